@@ -1,0 +1,128 @@
+"""ctypes binding of libgpmi355x.so (include/gpmi.h).
+
+The library is built in-tree by `gaussian_process_amd/csrc/Makefile`
+(`python -m gaussian_process_amd.build` or `__graft_entry__.build()`).  There is
+no CPU fallback: if the library is missing or a call fails, the shim raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpmi355x.so")
+
+GPMI_OK, GPMI_ERR_NOT_PD, GPMI_ERR_BAD_ARG, GPMI_ERR_RUNTIME = 0, 1, 2, 3
+ABI_VERSION = 1
+
+# stage-timer slots (enum in gpmi.h)
+T_KBUILD, T_CHOL, T_CHOL_PANEL, T_CHOL_TRAIL, T_LML, T_KS, T_SOLVE_V, T_MEANVAR, \
+    T_ALPHA, T_POSTCHOL, T_TRAIL_LAUNCHES, T_TRAIL_FLOPS = range(12)
+T_COUNT = 16
+TIMER_NAMES = ["kbuild", "chol", "chol_panel", "chol_trail", "lml", "ks", "solve_v", "meanvar",
+               "alpha", "postchol", "trail_launches", "trail_flops"]
+
+_dp = C.POINTER(C.c_double)
+_i64 = C.c_int64
+_vp = C.c_void_p
+
+# name -> (argtypes); every function returns int status unless noted
+SIGNATURES = {
+    "gpmi_abi_version": [],
+    "gpmi_device_count": [C.POINTER(C.c_int)],
+    "gpmi_ctx_create": [C.c_int, C.POINTER(_vp)],
+    "gpmi_ctx_destroy": [_vp],
+    "gpmi_set_option": [_vp, C.c_char_p, _i64],
+    "gpmi_rbf": [_vp, _dp, _i64, _dp, _i64, _i64, C.c_double, C.c_double, _dp],
+    "gpmi_set_train": [_vp, _dp, _i64, _i64, _dp],
+    "gpmi_factorize": [_vp, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(_i64)],
+    "gpmi_fit": [_vp, _dp, _i64, _i64, _dp, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(_i64)],
+    "gpmi_get_alpha": [_vp, _dp],
+    "gpmi_get_m": [_vp, _dp],
+    "gpmi_get_diag": [_vp, _dp],
+    "gpmi_get_factor_block": [_vp, _i64, _i64, _i64, _i64, _dp],
+    "gpmi_set_test": [_vp, _dp, _i64],
+    "gpmi_predict_resident": [_vp, _dp, _dp, C.c_int],
+    "gpmi_predict": [_vp, _dp, _i64, _dp, _dp, C.c_int],
+    "gpmi_post_chol": [_vp, C.c_double, _dp, C.POINTER(_i64)],
+    "gpmi_lml_batch": [_vp, _dp, _i64, _dp, C.POINTER(C.c_int)],
+    "gpmi_get_timers": [_vp, _dp, C.c_int],
+    "gpmi_sync": [_vp],
+    "gpmi_probe_mfma_f64": [_vp, _dp],
+    "gpmi_probe_hbm_write": [_vp, _i64, _dp],
+    "gpmi_dev_rbf_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, C.c_double, _vp, _i64],
+    "gpmi_dev_rbf_cross": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _vp, _i64],
+    "gpmi_dev_potrf_block": [_vp, _vp, _i64, _i64, _i64, _vp],
+    "gpmi_dev_trsm_block": [_vp, _vp, _i64, _vp, _i64, _i64, _i64],
+    "gpmi_dev_gemm_nt": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64],
+    "gpmi_dev_row_dots": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+class GpmiLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpmiLibraryMissing(
+            "libgpmi355x.so not found at %s -- build it with "
+            "`python -m gaussian_process_amd.build` (needs hipcc); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the ABI lacks a symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.gpmi_last_error.argtypes = []
+    lib.gpmi_last_error.restype = C.c_char_p
+    if lib.gpmi_abi_version() != ABI_VERSION:
+        raise RuntimeError("libgpmi355x.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return (load().gpmi_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(status, bad_pivot=None):
+    """Map a C status to the exception the reference would raise."""
+    if status == GPMI_OK:
+        return
+    msg = last_error()
+    if status == GPMI_ERR_NOT_PD:
+        # reference: np.linalg.cholesky raises LinAlgError (GP_regression.py:138,154)
+        err = np.linalg.LinAlgError("Matrix is not positive definite")
+        err.bad_pivot = bad_pivot
+        raise err
+    if status == GPMI_ERR_BAD_ARG:
+        raise ValueError(msg or "bad argument")
+    raise RuntimeError(msg or "HIP runtime error")
+
+
+def as_f64(a, ndim=None, name="array"):
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and arr.ndim != ndim:
+        raise ValueError("%s must be %d-dimensional, got shape %s" % (name, ndim, arr.shape))
+    return arr
+
+
+def ptr(arr):
+    return arr.ctypes.data_as(_dp)
+
+
+def scalar(x, name="value"):
+    """Hyper-parameters may arrive as 0-d / 1-element arrays (l[i] at
+    tune_hyperparms_regression.py:369; np.random.uniform(0,5,1) at :408)."""
+    a = np.asarray(x, dtype=np.float64)
+    if a.size != 1:
+        raise ValueError("%s must be a scalar, got shape %s" % (name, a.shape))
+    return float(a.reshape(()))

@@ -1,0 +1,262 @@
+// fp64 MFMA GEMM  C (M x N) op= A (M x K) * B (N x K)^T  for gfx950.
+//
+// This is the Cholesky trailing update (SYRK when A == B, lower tiles only),
+// the panel-internal rank-64 updates and the TRSM sweep's updates.  Both
+// operands are K-contiguous row slices of the row-major factor, so the same
+// staging serves A and B.
+//
+// Block = 256 threads = 4 wavefronts (2 x 2), tile 128 x (32*NI), K step 16.
+// Each wavefront owns a 64 x (16*NI) sub-tile = 4 x NI accumulators of
+// v_mfma_f64_16x16x4_f64 (4 f64 = 8 VGPRs each).
+//
+// LDS image of one operand tile for one K step: [kp = 0..7][row slot][2 f64],
+// i.e. 16-byte k-pairs, slot = row ^ kp.  Lane l of an MFMA reads row l&15,
+// k-pair 4t + (l>>4): one ds_read_b128 feeds two MFMAs (the k order inside a
+// K step is permuted identically for A and B, which leaves the sum unchanged).
+// With the XOR both the ds_write_b128 of the coalesced staging (8 lanes = one
+// 128-byte row segment) and the ds_read_b128 fragment reads are conflict-free.
+//
+// Tile order: 1-D grid; block b runs on XCD group b % 8 (round-robin dispatch,
+// a speed assumption only), and each group walks whole S x S super-tiles so
+// that the blocks resident on one XCD share A/B row slabs in its L2.
+#include "gpmi_internal.h"
+
+namespace gpmi {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int BK = 16;
+constexpr int KP = BK / 2;  // k-pairs per K step
+
+struct GemmDev {
+    double* C;
+    const double* A;
+    const double* B;
+    int64_t ldc, lda, ldb;
+    int Tm, Tn;        // tiles in M, N
+    int nchunks;       // K / 16
+    int mode, lower;
+    int64_t diag_off;
+    int S, logS;       // super-tile edge (tiles)
+    int SM, SN;        // super-tiles in M, N
+    int tri;           // triangular super-tile enumeration
+    int nsuper;
+};
+
+__device__ __forceinline__ bool map_tile(const GemmDev& p, int& ti, int& tj) {
+    const int b = blockIdx.x;
+    const int xcd = b & 7;
+    const int w = b >> 3;
+    const int S2 = p.S * p.S;
+    const int s = (w / S2) * 8 + xcd;
+    if (s >= p.nsuper) return false;
+    const int q = w % S2;
+    int si, sj;
+    if (p.tri) {
+        si = (int)((sqrtf(8.f * (float)s + 1.f) - 1.f) * 0.5f);
+        while ((si + 1) * (si + 2) / 2 <= s) ++si;
+        while (si * (si + 1) / 2 > s) --si;
+        sj = s - si * (si + 1) / 2;
+    } else {
+        si = s / p.SN;
+        sj = s - si * p.SN;
+    }
+    ti = si * p.S + (q >> p.logS);
+    tj = sj * p.S + (q & (p.S - 1));
+    return ti < p.Tm && tj < p.Tn;
+}
+
+template <int NI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
+    constexpr int TM = 128;
+    constexpr int TN = 32 * NI;
+    constexpr int A_SLOTS = KP * TM;          // 16-byte slots per stage
+    constexpr int B_SLOTS = KP * TN;
+    constexpr int A_LD = TM * KP / 256;       // staging loads per thread
+    constexpr int B_LD = TN * KP / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    d2* smem = reinterpret_cast<d2*>(smem_raw);
+    // layout: [stage][A slots | B slots]
+    constexpr int STAGE = A_SLOTS + B_SLOTS;
+
+    int ti, tj;
+    if (!map_tile(p, ti, tj)) return;
+    if (p.lower) {
+        // skip tiles entirely above {col <= row + diag_off}
+        const int64_t min_col = (int64_t)tj * TN;
+        const int64_t max_row = (int64_t)ti * TM + TM - 1;
+        if (min_col > max_row + p.diag_off) return;
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = (wave >> 1) * 64;            // wave row offset in tile
+    const int wc = (wave & 1) * (16 * NI);      // wave col offset in tile
+    const int fr = lane & 15;
+    const int fg = lane >> 4;
+
+    const double* Ag = p.A + (int64_t)ti * TM * p.lda;
+    const double* Bg = p.B + (int64_t)tj * TN * p.ldb;
+
+    // staging assignment: piece = tid + 256*i -> row = piece>>3, kp = piece&7
+    const int st_kp = tid & 7;
+    const int st_row = tid >> 3;                // + 32*i
+    const double* a_src = Ag + (int64_t)st_row * p.lda + st_kp * 2;
+    const double* b_src = Bg + (int64_t)st_row * p.ldb + st_kp * 2;
+
+    d2 ra[A_LD], rb[B_LD];
+    auto load_stage = [&](int chunk) {
+        const int k0 = chunk * BK;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            ra[i] = *reinterpret_cast<const d2*>(a_src + (int64_t)(32 * i) * p.lda + k0);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            rb[i] = *reinterpret_cast<const d2*>(b_src + (int64_t)(32 * i) * p.ldb + k0);
+    };
+    auto write_stage = [&](int buf) {
+        d2* sa = smem + buf * STAGE;
+        d2* sb = sa + A_SLOTS;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int row = st_row + 32 * i;
+            sa[st_kp * TM + (row ^ st_kp)] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int row = st_row + 32 * i;
+            sb[st_kp * TN + (row ^ st_kp)] = rb[i];
+        }
+    };
+
+    d4 acc[4][NI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = d4{0., 0., 0., 0.};
+
+    load_stage(0);
+    write_stage(0);
+    __syncthreads();
+
+    const int nch = p.nchunks;
+    for (int c = 0; c < nch; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nch) load_stage(c + 1);
+        const d2* sa = smem + buf * STAGE;
+        const d2* sb = sa + A_SLOTS;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int kp = 4 * t + fg;
+            d2 fa[4], fb[NI];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = sa[kp * TM + ((wr + 16 * i + fr) ^ kp)];
+#pragma unroll
+            for (int j = 0; j < NI; ++j) fb[j] = sb[kp * TN + ((wc + 16 * j + fr) ^ kp)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nch) write_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = 4*v + (lane>>4)
+    double* Cg = p.C + ((int64_t)ti * TM + wr) * p.ldc + (int64_t)tj * TN + wc;
+    if (p.mode == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double* ptr = Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr;
+                    *ptr = *ptr - acc[i][j][v];
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    double* ptr = Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr;
+                    *ptr = acc[i][j][v];
+                }
+    }
+}
+
+static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
+    p.C = a.C; p.A = a.A; p.B = a.B;
+    p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
+    p.Tm = (int)(a.M / 128);
+    p.Tn = (int)(a.N / TN);
+    p.nchunks = (int)(a.K / BK);
+    p.mode = a.mode;
+    p.lower = a.lower;
+    p.diag_off = a.diag_off;
+    // triangular super-tile enumeration only for square tiles on the diagonal
+    // (and only when the region is not a tall skinny strip, where most
+    // triangular super-tiles would be empty)
+    p.tri = (a.lower && TN == 128 && a.diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
+    int S = 8;
+    for (;; S >>= 1) {
+        const int SM = (p.Tm + S - 1) / S, SN = (p.Tn + S - 1) / S;
+        const int ns = p.tri ? SM * (SM + 1) / 2 : SM * SN;
+        if (ns >= 32 || S == 1) {
+            p.S = S; p.SM = SM; p.SN = SN; p.nsuper = ns;
+            break;
+        }
+    }
+    p.logS = (p.S == 8) ? 3 : (p.S == 4) ? 2 : (p.S == 2) ? 1 : 0;
+    nblocks = ((p.nsuper + 7) / 8) * 8 * p.S * p.S;
+}
+
+hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipSuccess;
+    if (a.M % 128 || a.N % 64 || a.K % BK) return hipErrorInvalidValue;
+    GemmDev p;
+    int nblocks;
+    if (a.N % 128 == 0) {
+        plan(a, 128, p, nblocks);
+        constexpr size_t lds = 2 * (KP * 128 + KP * 128) * 16;
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3(nblocks), dim3(256), lds, s, p);
+    } else {
+        plan(a, 64, p, nblocks);
+        constexpr size_t lds = 2 * (KP * 128 + KP * 64) * 16;
+        hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3(nblocks), dim3(256), lds, s, p);
+    }
+    return hipGetLastError();
+}
+
+double gemm_nt_flops(const GemmArgs& a) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0.;
+    const int TN = (a.N % 128 == 0) ? 128 : 64;
+    const int64_t Tm = a.M / 128, Tn = a.N / TN;
+    int64_t tiles = 0;
+    for (int64_t ti = 0; ti < Tm; ++ti) {
+        if (!a.lower) { tiles += Tn; continue; }
+        // tiles tj with tj*TN <= ti*128 + 127 + diag_off
+        int64_t lim = (ti * 128 + 127 + a.diag_off);
+        if (lim < 0) continue;
+        int64_t cnt = lim / TN + 1;
+        tiles += cnt < Tn ? cnt : Tn;
+    }
+    return 2.0 * (double)tiles * 128.0 * TN * (double)a.K;
+}
+
+}  // namespace gpmi

@@ -1,0 +1,752 @@
+// C-ABI of libgpmi355x.so (see include/gpmi.h) and the single-GPU drivers:
+// blocked right-looking Cholesky, the TRSM sweep for v = L^-1 K_s, and the
+// glue that keeps the reference's call surface (GP_regression.py:109-156,
+// tune_hyperparms_regression.py:292-313) reachable through plain C.
+//
+// Data layout in HBM (one context):
+//   A   (Np + 128) x ldA   row-major, ldA = Np + ld_pad.  Rows/cols < N hold
+//       K + s*I (lower tiles only) and, after gpmi_factorize, L.  Np = N rounded
+//       up to 128; the padding is the identity, so every block operation works
+//       on whole tiles.  Row Np carries y: the factorisation treats it as one
+//       more row of the panel, so when it finishes that row holds
+//       m = L^-1 y (forward substitution folded into the sweep, no extra pass).
+//   V   n_p x ldV          row-major, row i = K(x*_i, X) then (L^-1 K_s)[:, i]
+//       (v transposed: both GEMM operands of the sweep stay K-contiguous).
+//   P   n_p x ldP          posterior covariance / its factor (gpmi_post_chol).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/gpmi.h"
+#include "gpmi_internal.h"
+
+using namespace gpmi;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail_runtime(hipError_t e, const char* what) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+    g_err = buf;
+    return GPMI_ERR_RUNTIME;
+}
+int fail_arg(const char* what) {
+    g_err = what;
+    return GPMI_ERR_BAD_ARG;
+}
+
+#define HIP_TRY(expr)                                             \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return fail_runtime(_e, #expr);     \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct TimedSpan { hipEvent_t a, b; int slot; };
+
+}  // namespace
+
+struct gpmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // options
+    int64_t nb = 512;       // outer block width of the Cholesky (multiple of 128)
+    int64_t ld_pad = 544;   // doubles added to every leading dimension
+    int timing = 1;
+    // training set / factor
+    int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
+    bool have_train = false, have_factor = false;
+    double sig2 = 1.0, coef = -0.5;
+    DevBuf X, y, A, info, red;
+    // test set
+    int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
+    bool have_test = false, have_v = false;
+    DevBuf Xs, V, P, vec, dense;
+    // timers
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<TimedSpan> spans;
+    double stage_ms[GPMI_T_COUNT] = {0};
+
+    hipEvent_t new_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
+    size_t span_begin(int slot) {
+        if (!timing) return 0;
+        TimedSpan s{new_event(), new_event(), slot};
+        (void)hipEventRecord(s.a, stream);
+        spans.push_back(s);
+        return spans.size() - 1;
+    }
+    void span_end(size_t idx) {
+        if (!timing) return;
+        (void)hipEventRecord(spans[idx].b, stream);
+    }
+    void timers_reset(std::initializer_list<int> slots) {
+        for (int s : slots) stage_ms[s] = 0.;
+    }
+    // call after the stream has been synchronised
+    void timers_collect() {
+        for (auto& s : spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) stage_ms[s.slot] += ms;
+        }
+        spans.clear();
+        ev_used = 0;
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Panel factorisation: the nb-wide block column whose diagonal block starts at
+// A (global column col_offset), `mrows` rows tall (mrows >= nb, multiple of
+// 128).  Right-looking in steps of 64 columns:
+//   potf2 of the 64x64 diagonal block, substitution-TRSM of every row below
+//   it, rank-64 MFMA update of the panel columns to the right.
+// ---------------------------------------------------------------------------
+hipError_t panel_factor(hipStream_t s, double* A, int64_t ld, int64_t nb, int64_t mrows,
+                        int64_t col_offset, int64_t* info) {
+    hipError_t e;
+    for (int64_t j = 0; j < nb; j += IB) {
+        double* Ajj = A + j * ld + j;
+        if ((e = launch_potf2_64(s, Ajj, ld, col_offset + j, info)) != hipSuccess) return e;
+        const int64_t below = mrows - j - IB;
+        if (below > 0 &&
+            (e = launch_trsm_rlt64(s, Ajj, ld, A + (j + IB) * ld + j, ld, below)) != hipSuccess)
+            return e;
+        const int64_t wrem = nb - j - IB;
+        if (wrem > 0) {
+            // rows start at the 128-aligned row at or above j+64: the extra 64 rows
+            // (when j+64 is not a multiple of 128) lie above the diagonal of the
+            // updated columns and are never read.
+            const int64_t r0 = (j + IB) / TILE * TILE;
+            GemmArgs g;
+            g.C = A + r0 * ld + (j + IB);
+            g.A = A + r0 * ld + j;
+            g.B = A + (j + IB) * ld + j;
+            g.ldc = g.lda = g.ldb = ld;
+            g.M = mrows - r0; g.N = wrem; g.K = IB;
+            g.mode = 0; g.lower = 1; g.diag_off = r0 - (j + IB);
+            if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+// X (m x nb) <- X * L^-T, L nb x nb lower; m multiple of 128, nb multiple of 64
+hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
+                      int64_t m, int64_t nb) {
+    hipError_t e;
+    for (int64_t j = 0; j < nb; j += IB) {
+        if ((e = launch_trsm_rlt64(s, L + j * ldl + j, ldl, X + j, ldx, m)) != hipSuccess) return e;
+        const int64_t wrem = nb - j - IB;
+        if (wrem > 0) {
+            GemmArgs g;
+            g.C = X + (j + IB);
+            g.A = X + j;
+            g.B = L + (j + IB) * ldl + j;
+            g.ldc = g.lda = ldx; g.ldb = ldl;
+            g.M = m; g.N = wrem; g.K = IB;
+            g.mode = 0; g.lower = 0; g.diag_off = 0;
+            if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+// In-place blocked right-looking Cholesky of the leading ncols x ncols block of
+// A; rows ncols..nrows-1 are carried along (they end up multiplied by L^-T).
+hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows,
+                            int64_t* info, bool account) {
+    hipError_t e;
+    hipStream_t s = c->stream;
+    for (int64_t k = 0; k < ncols; k += c->nb) {
+        const int64_t nb = std::min<int64_t>(c->nb, ncols - k);
+        size_t sp = c->span_begin(account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1);
+        e = panel_factor(s, A + k * ld + k, ld, nb, nrows - k, k, info);
+        c->span_end(sp);
+        if (e != hipSuccess) return e;
+        const int64_t r0 = k + nb;
+        if (r0 < nrows && r0 < ncols) {
+            GemmArgs g;
+            g.C = A + r0 * ld + r0;
+            g.A = A + r0 * ld + k;
+            g.B = g.A;
+            g.ldc = g.lda = g.ldb = ld;
+            g.M = nrows - r0; g.N = ncols - r0; g.K = nb;
+            g.mode = 0; g.lower = 1; g.diag_off = 0;
+            sp = c->span_begin(account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1);
+            e = launch_gemm_nt(s, g);
+            c->span_end(sp);
+            if (e != hipSuccess) return e;
+            if (account) {
+                c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
+                c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_flops(g);
+            }
+        }
+    }
+    return hipSuccess;
+}
+
+int ensure_train_buffers(gpmi_ctx* c) {
+    c->Np = round_up(c->N, TILE);
+    c->ldA = c->Np + c->ld_pad;
+    c->Mp = c->Np + TILE;
+    HIP_TRY(c->A.ensure((size_t)c->Mp * c->ldA * sizeof(double)));
+    HIP_TRY(c->info.ensure(sizeof(int64_t)));
+    HIP_TRY(c->red.ensure(16 * sizeof(double)));
+    return GPMI_OK;
+}
+
+// K build + Cholesky (+ forward solve through the y row) + LML on the stream
+int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
+                   int64_t* bad_pivot) {
+    if (!c->have_train) return fail_arg("gpmi_factorize: no training set (call gpmi_set_train)");
+    if (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma) || std::isnan(noise_var))
+        return fail_arg("gpmi_factorize: ell must be non-zero and hyper-parameters finite");
+    int rc = ensure_train_buffers(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    c->have_factor = false;
+    c->have_v = false;
+    c->timers_reset({GPMI_T_KBUILD, GPMI_T_CHOL, GPMI_T_CHOL_PANEL, GPMI_T_CHOL_TRAIL, GPMI_T_LML,
+                     GPMI_T_TRAIL_LAUNCHES, GPMI_T_TRAIL_FLOPS});
+    c->sig2 = sigma * sigma;
+    c->coef = -.5 * (1 / (ell * ell));      // GP_regression.py:19 evaluation order
+    double* A = c->A.as<double>();
+    const int64_t big = std::numeric_limits<int64_t>::max();
+    HIP_TRY(hipMemcpyAsync(c->info.p, &big, sizeof big, hipMemcpyHostToDevice, s));
+
+    size_t sp = c->span_begin(GPMI_T_KBUILD);
+    RbfArgs r;
+    r.A = r.B = c->X.as<double>();
+    r.nA = r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->Np; r.ncols = c->Np;
+    r.coef = c->coef; r.sig2 = c->sig2; r.diag_add = noise_var; r.symmetric = 1;
+    r.out = A; r.ld = c->ldA;
+    HIP_TRY(launch_rbf(s, r));
+    // the augmented rows: y then zeros
+    HIP_TRY(launch_fill_rows(s, A + c->Np * c->ldA, c->ldA, TILE, c->Np, 0.0));
+    HIP_TRY(launch_set_yrow(s, A + c->Np * c->ldA, c->y.as<double>(), c->N, c->Np));
+    c->span_end(sp);
+
+    sp = c->span_begin(GPMI_T_CHOL);
+    HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true));
+    c->span_end(sp);
+
+    sp = c->span_begin(GPMI_T_LML);
+    HIP_TRY(launch_lml_reduce(s, A, c->ldA, A + c->Np * c->ldA, c->N, c->red.as<double>()));
+    c->span_end(sp);
+
+    double red[2];
+    int64_t info;
+    HIP_TRY(hipMemcpyAsync(red, c->red.p, sizeof red, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof info, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->timers_collect();
+    if (info != big && info < c->N) {
+        if (bad_pivot) *bad_pivot = info + 1;
+        if (lml) *lml = std::numeric_limits<double>::quiet_NaN();
+        g_err = "Matrix is not positive definite";
+        return GPMI_ERR_NOT_PD;
+    }
+    if (bad_pivot) *bad_pivot = 0;
+    // tune_hyperparms_regression.py:312, with y^T alpha = m^T m
+    if (lml) *lml = -.5 * red[1] - red[0] - (double)c->N / 2.0 * std::log(2 * M_PI);
+    c->have_factor = true;
+    return GPMI_OK;
+}
+
+// v^T = K_s^T L^-T: right-looking sweep over the block columns of L
+hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
+    hipError_t e;
+    hipStream_t s = c->stream;
+    const double* A = c->A.as<double>();
+    const int64_t ld = c->ldA, Np = c->Np;
+    for (int64_t k = 0; k < Np; k += c->nb) {
+        const int64_t nb = std::min<int64_t>(c->nb, Np - k);
+        if ((e = trsm_block(s, A + k * ld + k, ld, V + k, ldv, m, nb)) != hipSuccess) return e;
+        const int64_t r0 = k + nb;
+        if (r0 < Np) {
+            GemmArgs g;
+            g.C = V + r0; g.A = V + k; g.B = A + r0 * ld + k;
+            g.ldc = g.lda = ldv; g.ldb = ld;
+            g.M = m; g.N = Np - r0; g.K = nb;
+            g.mode = 0; g.lower = 0; g.diag_off = 0;
+            if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
+        }
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpmi_abi_version(void) { return GPMI_ABI_VERSION; }
+const char* gpmi_last_error(void) { return g_err.c_str(); }
+
+int gpmi_device_count(int* count) {
+    if (!count) return fail_arg("gpmi_device_count: null pointer");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail_runtime(e, "hipGetDeviceCount"); }
+    *count = n;
+    return GPMI_OK;
+}
+
+int gpmi_ctx_create(int device, gpmi_ctx** out) {
+    if (!out) return fail_arg("gpmi_ctx_create: null out pointer");
+    *out = nullptr;
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail_arg("gpmi_ctx_create: no such device");
+    HIP_TRY(hipSetDevice(device));
+    gpmi_ctx* c = new gpmi_ctx();
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail_runtime(e, "hipStreamCreate"); }
+    const char* env;
+    if ((env = getenv("GPMI_NB"))) c->nb = std::max<int64_t>(128, atoll(env) / 128 * 128);
+    if ((env = getenv("GPMI_LD_PAD"))) c->ld_pad = std::max<int64_t>(0, atoll(env) / 2 * 2);
+    *out = c;
+    return GPMI_OK;
+}
+
+int gpmi_ctx_destroy(gpmi_ctx* c) {
+    if (!c) return GPMI_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->X, &c->y, &c->A, &c->info, &c->red, &c->Xs, &c->V, &c->P, &c->vec, &c->dense})
+        b->release();
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GPMI_OK;
+}
+
+int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
+    if (!c || !name) return fail_arg("gpmi_set_option: null argument");
+    if (!strcmp(name, "nb")) {
+        if (value < 128 || value % 128) return fail_arg("nb must be a positive multiple of 128");
+        c->nb = value;
+    } else if (!strcmp(name, "ld_pad")) {
+        if (value < 0 || value % 2) return fail_arg("ld_pad must be even and >= 0");
+        c->ld_pad = value;
+        c->have_factor = c->have_v = false;
+    } else if (!strcmp(name, "timing")) {
+        c->timing = value ? 1 : 0;
+    } else {
+        return fail_arg("gpmi_set_option: unknown option");
+    }
+    return GPMI_OK;
+}
+
+int gpmi_sync(gpmi_ctx* c) {
+    if (!c) return fail_arg("gpmi_sync: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GPMI_OK;
+}
+
+int gpmi_rbf(gpmi_ctx* c, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
+             double sigma, double ell, double* out) {
+    if (!c || !a || !b || !out) return fail_arg("gpmi_rbf: null argument");
+    if (N < 0 || M < 0 || d <= 0) return fail_arg("gpmi_rbf: bad dimensions");
+    if (!(ell != 0.0)) return fail_arg("gpmi_rbf: ell must be non-zero");
+    if (N == 0 || M == 0) return GPMI_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf da, db, dout;
+    const int64_t Mp = round_up(M, TILE), ld = Mp + 32;
+    const int64_t chunk = std::max<int64_t>(TILE, std::min<int64_t>(round_up(N, TILE),
+                          ((int64_t)1 << 30) / (ld * 8) / TILE * TILE));
+    int rc = GPMI_OK;
+    hipError_t e;
+    do {
+        if ((e = da.ensure((size_t)N * d * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc a"); break; }
+        if ((e = db.ensure((size_t)M * d * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc b"); break; }
+        if ((e = dout.ensure((size_t)chunk * ld * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc out"); break; }
+        if ((e = hipMemcpyAsync(da.p, a, (size_t)N * d * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(db.p, b, (size_t)M * d * 8, hipMemcpyHostToDevice, s)) != hipSuccess) {
+            rc = fail_runtime(e, "hipMemcpy H2D"); break;
+        }
+        for (int64_t r0 = 0; r0 < N && rc == GPMI_OK; r0 += chunk) {
+            const int64_t rows = std::min(chunk, N - r0);
+            RbfArgs r;
+            r.A = da.as<double>(); r.B = db.as<double>();
+            r.nA = N; r.nB = M; r.d = d; r.row0 = r0; r.nrows = round_up(rows, TILE); r.ncols = Mp;
+            r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
+            r.out = dout.as<double>(); r.ld = ld;
+            if ((e = launch_rbf(s, r)) != hipSuccess) { rc = fail_runtime(e, "rbf kernel"); break; }
+            if ((e = hipMemcpy2DAsync(out + r0 * M, (size_t)M * 8, dout.p, (size_t)ld * 8, (size_t)M * 8,
+                                      (size_t)rows, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+                (e = hipStreamSynchronize(s)) != hipSuccess) {
+                rc = fail_runtime(e, "rbf D2H"); break;
+            }
+        }
+    } while (0);
+    (void)hipStreamSynchronize(s);
+    da.release(); db.release(); dout.release();
+    return rc;
+}
+
+int gpmi_set_train(gpmi_ctx* c, const double* X, int64_t N, int64_t d, const double* y) {
+    if (!c || !X || !y) return fail_arg("gpmi_set_train: null argument");
+    if (N <= 0 || d <= 0) return fail_arg("gpmi_set_train: N and d must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_train = c->have_factor = c->have_v = c->have_test = false;
+    HIP_TRY(c->X.ensure((size_t)N * d * 8));
+    HIP_TRY(c->y.ensure((size_t)N * 8));
+    HIP_TRY(hipMemcpyAsync(c->X.p, X, (size_t)N * d * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->N = N; c->d = d;
+    c->have_train = true;
+    return GPMI_OK;
+}
+
+int gpmi_factorize(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
+                   int64_t* bad_pivot) {
+    if (!c) return fail_arg("gpmi_factorize: null context");
+    HIP_TRY(hipSetDevice(c->device));
+    return factorize_impl(c, sigma, ell, noise_var, lml, bad_pivot);
+}
+
+int gpmi_fit(gpmi_ctx* c, const double* X, int64_t N, int64_t d, const double* y, double sigma,
+             double ell, double noise_var, double* lml, int64_t* bad_pivot) {
+    int rc = gpmi_set_train(c, X, N, d, y);
+    if (rc) return rc;
+    return gpmi_factorize(c, sigma, ell, noise_var, lml, bad_pivot);
+}
+
+int gpmi_get_m(gpmi_ctx* c, double* m_out) {
+    if (!c || !m_out) return fail_arg("gpmi_get_m: null argument");
+    if (!c->have_factor) return fail_arg("gpmi_get_m: no factorisation resident");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(m_out, c->A.as<double>() + c->Np * c->ldA, (size_t)c->N * 8,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GPMI_OK;
+}
+
+int gpmi_get_diag(gpmi_ctx* c, double* diag_out) {
+    if (!c || !diag_out) return fail_arg("gpmi_get_diag: null argument");
+    if (!c->have_factor) return fail_arg("gpmi_get_diag: no factorisation resident");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpy2DAsync(diag_out, 8, c->A.p, (size_t)(c->ldA + 1) * 8, 8, (size_t)c->N,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GPMI_OK;
+}
+
+int gpmi_get_factor_block(gpmi_ctx* c, int64_t r0, int64_t r1, int64_t c0, int64_t c1, double* out) {
+    if (!c || !out) return fail_arg("gpmi_get_factor_block: null argument");
+    if (!c->have_factor) return fail_arg("gpmi_get_factor_block: no factorisation resident");
+    if (r0 < 0 || c0 < 0 || r1 > c->N || c1 > c->N || r0 > r1 || c0 > c1)
+        return fail_arg("gpmi_get_factor_block: block out of range");
+    if (r0 == r1 || c0 == c1) return GPMI_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)(r1 - r0) * (c1 - c0) * 8;
+    HIP_TRY(c->dense.ensure(bytes));
+    HIP_TRY(launch_extract(c->stream, c->A.as<double>(), c->ldA, r0, r1, c0, c1, c->dense.as<double>(), 1));
+    HIP_TRY(hipMemcpyAsync(out, c->dense.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return GPMI_OK;
+}
+
+int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
+    if (!c || !alpha_out) return fail_arg("gpmi_get_alpha: null argument");
+    if (!c->have_factor) return fail_arg("gpmi_get_alpha: no factorisation resident");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->timers_reset({GPMI_T_ALPHA});
+    HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
+    double* x = c->vec.as<double>();
+    // padded tail of m is zero (identity padding), so the padded system stays consistent
+    HIP_TRY(hipMemcpyAsync(x, c->A.as<double>() + c->Np * c->ldA, (size_t)c->Np * 8,
+                           hipMemcpyDeviceToDevice, s));
+    size_t sp = c->span_begin(GPMI_T_ALPHA);
+    HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), c->ldA, x, c->Np));
+    c->span_end(sp);
+    HIP_TRY(hipMemcpyAsync(alpha_out, x, (size_t)c->N * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->timers_collect();
+    return GPMI_OK;
+}
+
+int gpmi_set_test(gpmi_ctx* c, const double* Xs, int64_t n) {
+    if (!c || !Xs) return fail_arg("gpmi_set_test: null argument");
+    if (!c->have_train) return fail_arg("gpmi_set_test: set the training set first");
+    if (n <= 0) return fail_arg("gpmi_set_test: n must be positive");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_test = c->have_v = false;
+    HIP_TRY(c->Xs.ensure((size_t)n * c->d * 8));
+    HIP_TRY(hipMemcpyAsync(c->Xs.p, Xs, (size_t)n * c->d * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n = n;
+    c->np_ = round_up(n, TILE);
+    c->have_test = true;
+    return GPMI_OK;
+}
+
+int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
+    if (!c) return fail_arg("gpmi_predict: null context");
+    if (!c->have_factor) return fail_arg("gpmi_predict: no factorisation resident (call gpmi_factorize)");
+    if (!c->have_test) return fail_arg("gpmi_predict: no test set (call gpmi_set_test)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->timers_reset({GPMI_T_KS, GPMI_T_SOLVE_V, GPMI_T_MEANVAR});
+    c->have_v = false;
+    c->ldV = c->Np + c->ld_pad;
+    HIP_TRY(c->V.ensure((size_t)c->np_ * c->ldV * 8));
+    HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
+    double* V = c->V.as<double>();
+
+    size_t sp = c->span_begin(GPMI_T_KS);
+    RbfArgs r;
+    r.A = c->Xs.as<double>(); r.B = c->X.as<double>();
+    r.nA = c->n; r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->np_; r.ncols = c->Np;
+    r.coef = c->coef; r.sig2 = c->sig2; r.diag_add = 0.; r.symmetric = 0;
+    r.out = V; r.ld = c->ldV;
+    HIP_TRY(launch_rbf(s, r));
+    c->span_end(sp);
+
+    sp = c->span_begin(GPMI_T_SOLVE_V);
+    HIP_TRY(solve_sweep(c, V, c->ldV, c->np_));
+    c->span_end(sp);
+
+    sp = c->span_begin(GPMI_T_MEANVAR);
+    double* dot = c->vec.as<double>();
+    double* sq = dot + c->np_;
+    HIP_TRY(launch_row_dots(s, V, c->ldV, c->np_, c->Np, c->A.as<double>() + c->Np * c->ldA, dot, sq));
+    c->span_end(sp);
+
+    std::vector<double> h(2 * (size_t)c->np_);
+    HIP_TRY(hipMemcpyAsync(h.data(), dot, h.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->timers_collect();
+    c->have_v = true;
+    for (int64_t i = 0; i < c->n; ++i) {
+        if (mu) mu[i] = h[i];
+        if (out2) {
+            const double var = c->sig2 - h[c->np_ + i];   // diag(K_ss) == sigma^2 exactly (GP_regression.py:147)
+            out2[i] = want_sd ? std::sqrt(var) : var;      // sqrt(<0) -> NaN like np.sqrt (:148)
+        }
+    }
+    return GPMI_OK;
+}
+
+int gpmi_predict(gpmi_ctx* c, const double* Xs, int64_t n, double* mu, double* out2, int want_sd) {
+    int rc = gpmi_set_test(c, Xs, n);
+    if (rc) return rc;
+    return gpmi_predict_resident(c, mu, out2, want_sd);
+}
+
+int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot) {
+    if (!c || !L_out) return fail_arg("gpmi_post_chol: null argument");
+    if (!c->have_v) return fail_arg("gpmi_post_chol: run gpmi_predict first");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->timers_reset({GPMI_T_POSTCHOL});
+    const int64_t np_ = c->np_, n = c->n;
+    c->ldP = np_ + 32;
+    HIP_TRY(c->P.ensure((size_t)np_ * c->ldP * 8));
+    double* P = c->P.as<double>();
+    const int64_t big = std::numeric_limits<int64_t>::max();
+    HIP_TRY(hipMemcpyAsync(c->info.p, &big, sizeof big, hipMemcpyHostToDevice, s));
+    size_t sp = c->span_begin(GPMI_T_POSTCHOL);
+    RbfArgs r;   // K_ss + jitter*I, lower tiles (GP_regression.py:128,154)
+    r.A = r.B = c->Xs.as<double>();
+    r.nA = r.nB = n; r.d = c->d; r.row0 = 0; r.nrows = np_; r.ncols = np_;
+    r.coef = c->coef; r.sig2 = c->sig2; r.diag_add = jitter; r.symmetric = 1;
+    r.out = P; r.ld = c->ldP;
+    HIP_TRY(launch_rbf(s, r));
+    GemmArgs g;  // P -= v^T v  (rows of V are the columns of v)
+    g.C = P; g.A = g.B = c->V.as<double>();
+    g.ldc = c->ldP; g.lda = g.ldb = c->ldV;
+    g.M = g.N = np_; g.K = c->Np; g.mode = 0; g.lower = 1; g.diag_off = 0;
+    HIP_TRY(launch_gemm_nt(s, g));
+    HIP_TRY(cholesky_inplace(c, P, c->ldP, np_, np_, c->info.as<int64_t>(), false));
+    c->span_end(sp);
+    HIP_TRY(c->dense.ensure((size_t)n * n * 8));
+    HIP_TRY(launch_extract(s, P, c->ldP, 0, n, 0, n, c->dense.as<double>(), 1));
+    int64_t info;
+    HIP_TRY(hipMemcpyAsync(L_out, c->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof info, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->timers_collect();
+    if (info != big && info < n) {
+        if (bad_pivot) *bad_pivot = info + 1;
+        g_err = "Matrix is not positive definite";
+        return GPMI_ERR_NOT_PD;
+    }
+    if (bad_pivot) *bad_pivot = 0;
+    return GPMI_OK;
+}
+
+int gpmi_lml_batch(gpmi_ctx* c, const double* triples, int64_t T, double* lml_out, int* status_out) {
+    if (!c || !triples || !lml_out) return fail_arg("gpmi_lml_batch: null argument");
+    if (T < 0) return fail_arg("gpmi_lml_batch: T < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    double acc[GPMI_T_COUNT] = {0};
+    for (int64_t t = 0; t < T; ++t) {
+        const double ell = triples[3 * t], sigma = triples[3 * t + 1], s2 = triples[3 * t + 2];
+        double lml = 0.;
+        int64_t bad = 0;
+        int rc = factorize_impl(c, sigma, ell, s2, &lml, &bad);
+        if (rc == GPMI_ERR_RUNTIME || rc == GPMI_ERR_BAD_ARG) return rc;
+        lml_out[t] = lml;
+        if (status_out) status_out[t] = rc;
+        for (int i = 0; i < GPMI_T_COUNT; ++i) acc[i] += c->stage_ms[i];
+    }
+    for (int i = 0; i < GPMI_T_COUNT; ++i) c->stage_ms[i] = acc[i];
+    return GPMI_OK;
+}
+
+int gpmi_get_timers(gpmi_ctx* c, double* stage_ms, int count) {
+    if (!c || !stage_ms) return fail_arg("gpmi_get_timers: null argument");
+    for (int i = 0; i < count; ++i) stage_ms[i] = i < GPMI_T_COUNT ? c->stage_ms[i] : 0.;
+    return GPMI_OK;
+}
+
+int gpmi_probe_mfma_f64(gpmi_ctx* c, double* tflops) {
+    if (!c || !tflops) return fail_arg("gpmi_probe_mfma_f64: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->red.ensure(16 * 8));
+    hipStream_t s = c->stream;
+    const int iters = 4096, blocks = 256 * 2;   // 2 blocks of 4 waves per CU
+    HIP_TRY(launch_probe_mfma(s, c->red.as<double>(), 64, blocks));   // warm-up
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, s));
+    HIP_TRY(launch_probe_mfma(s, c->red.as<double>(), iters, blocks));
+    HIP_TRY(hipEventRecord(b, s));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 8 /*mfma*/ * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    return GPMI_OK;
+}
+
+int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
+    if (!c || !gbps || bytes < 4096) return fail_arg("gpmi_probe_hbm_write: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf buf;
+    HIP_TRY(buf.ensure((size_t)bytes));
+    hipError_t e = launch_probe_write(s, buf.as<double>(), bytes / 8);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    if (e == hipSuccess) e = launch_probe_write(s, buf.as<double>(), bytes / 8);
+    (void)hipEventRecord(b, s);
+    hipError_t e2 = hipEventSynchronize(b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    buf.release();
+    if (e != hipSuccess) return fail_runtime(e, "probe write");
+    if (e2 != hipSuccess) return fail_runtime(e2, "probe write sync");
+    *gbps = (double)bytes / (ms * 1e-3) / 1e9;
+    return GPMI_OK;
+}
+
+// ---- device-pointer block primitives (multi-GPU driver) -------------------------
+int gpmi_dev_rbf_rows(void* stream, const double* X_dev, int64_t N, int64_t d, int64_t row0,
+                      int64_t nrows, int64_t ncols, double sigma, double ell, double noise_var,
+                      double* out_dev, int64_t ld) {
+    if (!X_dev || !out_dev) return fail_arg("gpmi_dev_rbf_rows: null pointer");
+    if (nrows % TILE || ncols % TILE || row0 % TILE || ld < ncols || ld % 2)
+        return fail_arg("gpmi_dev_rbf_rows: sizes must be multiples of 128");
+    RbfArgs r;
+    r.A = r.B = X_dev; r.nA = r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
+    r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = noise_var; r.symmetric = 1;
+    r.out = out_dev; r.ld = ld;
+    HIP_TRY(launch_rbf((hipStream_t)stream, r));
+    return GPMI_OK;
+}
+
+int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const double* X_dev, int64_t N,
+                       int64_t d, int64_t row0, int64_t nrows, int64_t ncols, double sigma, double ell,
+                       double* out_dev, int64_t ld) {
+    if (!Xs_dev || !X_dev || !out_dev) return fail_arg("gpmi_dev_rbf_cross: null pointer");
+    if (nrows % TILE || ncols % TILE || ld < ncols || ld % 2)
+        return fail_arg("gpmi_dev_rbf_cross: sizes must be multiples of 128");
+    RbfArgs r;
+    r.A = Xs_dev; r.B = X_dev; r.nA = n; r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
+    r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
+    r.out = out_dev; r.ld = ld;
+    HIP_TRY(launch_rbf((hipStream_t)stream, r));
+    return GPMI_OK;
+}
+
+int gpmi_dev_potrf_block(void* stream, double* A_dev, int64_t ld, int64_t nb, int64_t col_offset,
+                         int64_t* info_dev) {
+    if (!A_dev || !info_dev) return fail_arg("gpmi_dev_potrf_block: null pointer");
+    if (nb <= 0 || nb % TILE || ld % 2) return fail_arg("gpmi_dev_potrf_block: nb must be a multiple of 128");
+    HIP_TRY(panel_factor((hipStream_t)stream, A_dev, ld, nb, nb, col_offset, info_dev));
+    return GPMI_OK;
+}
+
+int gpmi_dev_trsm_block(void* stream, const double* L_dev, int64_t ldl, double* X_dev, int64_t ldx,
+                        int64_t m, int64_t nb) {
+    if (!L_dev || !X_dev) return fail_arg("gpmi_dev_trsm_block: null pointer");
+    if (m < 0 || m % TILE || nb <= 0 || nb % IB || ldl % 2 || ldx % 2)
+        return fail_arg("gpmi_dev_trsm_block: m must be a multiple of 128, nb of 64");
+    if (m == 0) return GPMI_OK;
+    HIP_TRY(trsm_block((hipStream_t)stream, L_dev, ldl, X_dev, ldx, m, nb));
+    return GPMI_OK;
+}
+
+int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                     const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K, int lower,
+                     int64_t diag_off) {
+    if (!C_dev || !A_dev || !B_dev) return fail_arg("gpmi_dev_gemm_nt: null pointer");
+    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2)
+        return fail_arg("gpmi_dev_gemm_nt: M%128, N%64, K%16 must be 0");
+    GemmArgs g;
+    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = diag_off;
+    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
+    return GPMI_OK;
+}
+
+int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
+                      const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
+    if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");
+    if (ncols % 2 || ld % 2) return fail_arg("gpmi_dev_row_dots: ncols and ld must be even");
+    HIP_TRY(launch_row_dots((hipStream_t)stream, V_dev, ld, nrows, ncols, m_dev, dot_out_dev, sq_out_dev));
+    return GPMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+// Internal declarations shared by the translation units of libgpmi355x.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, v_mfma_f64_16x16x4_f64.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpmi {
+
+constexpr int TILE = 128;   // row / column padding granule of every matrix
+constexpr int IB = 64;      // inner (register-resident) panel width
+
+// ---- gemm_nt.hip ----------------------------------------------------------
+// C (M x N) op= A (M x K) * B (N x K)^T, all row-major.  M multiple of 128,
+// N multiple of 64, K multiple of 16.  mode 0: C -= A*B^T; mode 1: C = A*B^T.
+// lower != 0: skip tiles lying entirely above {col <= row + diag_off}.
+struct GemmArgs {
+    double* C;
+    const double* A;
+    const double* B;
+    int64_t ldc, lda, ldb;
+    int64_t M, N, K;
+    int mode;
+    int lower;
+    int64_t diag_off;
+};
+hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
+// number of tiles the launch actually computes (for flop accounting)
+double gemm_nt_flops(const GemmArgs& a);
+
+// ---- panel.hip -------------------------------------------------------------
+// Cholesky of one 64x64 diagonal block in place (lower), one wavefront.
+hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_offset,
+                           int64_t* info_dev);
+// X (m x 64) <- X * L^-T, L 64x64 lower; m multiple of 64.
+hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
+                             int64_t m);
+
+// ---- rbf.hip ---------------------------------------------------------------
+struct RbfArgs {
+    const double* A;   // rows of the output: nA x d (row-major, device)
+    const double* B;   // cols of the output: nB x d
+    int64_t nA, nB, d;
+    int64_t row0;      // first output row (index into A)
+    int64_t nrows;     // rows to produce (multiple of 128 incl. padding)
+    int64_t ncols;     // cols to produce (multiple of 128 incl. padding)
+    double coef;       // -.5 * (1 / l^2)
+    double sig2;       // sigma^2
+    double diag_add;   // + s on global row == col (symmetric build only)
+    int symmetric;     // 1: A==B, lower tiles only, identity padding
+    double* out;       // nrows x ld, out(0,0) is element (row0, 0)
+    int64_t ld;
+};
+hipError_t launch_rbf(hipStream_t s, const RbfArgs& a);
+
+// ---- solve.hip -------------------------------------------------------------
+// dot[i] = sum_j V[i][j]*m[j], sq[i] = sum_j V[i][j]^2, j < ncols (fixed order)
+hipError_t launch_row_dots(hipStream_t s, const double* V, int64_t ld, int64_t nrows,
+                           int64_t ncols, const double* m, double* dot, double* sq);
+// out[0] = sum_{i<n} log(A[i*(ld+1)]), out[1] = sum_{i<n} m[i]^2 (deterministic)
+hipError_t launch_lml_reduce(hipStream_t s, const double* A, int64_t ld, const double* m,
+                             int64_t n, double* out2);
+// backward substitution  L^T x = b  (x overwrites b); n multiple of 64
+hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b, int64_t n);
+// fill helpers
+hipError_t launch_fill_rows(hipStream_t s, double* A, int64_t ld, int64_t nrows, int64_t ncols,
+                            double value);
+hipError_t launch_set_yrow(hipStream_t s, double* row, const double* y, int64_t N, int64_t ncols);
+// C = diag_val*I + Kss - G on the lower tiles (post-covariance assembly)
+hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0, int64_t r1,
+                          int64_t c0, int64_t c1, double* out, int lower_only);
+
+// ---- probes ----------------------------------------------------------------
+hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks);
+hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles);
+
+}  // namespace gpmi

@@ -1,0 +1,214 @@
+// Small HBM-bound kernels around the factorisation: reductions for the
+// predictive mean / variance and the log-marginal-likelihood, the backward
+// substitution for alpha, fills and extraction, and the two peak probes.
+// All reductions use a fixed summation tree (no atomics), so results are
+// reproducible run to run.
+#include "gpmi_internal.h"
+
+namespace gpmi {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// fixed-order block reduction of two values; result valid in thread 0
+template <int THREADS>
+__device__ __forceinline__ void block_reduce2(double& a, double& b, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0., sb = 0.;
+        for (int w = 0; w < THREADS / 64; ++w) { sa += sh[2 * w]; sb += sh[2 * w + 1]; }
+        a = sa; b = sb;
+    }
+}
+
+// ---- mean / variance: row dots of V (n x ncols) with m -----------------------
+// reference: mu = K_s.T @ alpha (GP_regression.py:143) evaluated as v.T @ m with
+// v = L^-1 K_s, m = L^-1 y (same quantity, one solve fewer), and
+// sum(v**2, axis=0) of :147.
+__global__ __launch_bounds__(256) void row_dots_kernel(const double* V, int64_t ld, int64_t ncols,
+                                                        const double* m, double* dot, double* sq) {
+    __shared__ double sh[8];
+    const double* row = V + (int64_t)blockIdx.x * ld;
+    double a = 0., b = 0.;
+    for (int64_t j = 2 * (int64_t)threadIdx.x; j < ncols; j += 512) {
+        const d2 v = *reinterpret_cast<const d2*>(row + j);
+        const d2 mm = *reinterpret_cast<const d2*>(m + j);
+        a = fma(v.x, mm.x, a); a = fma(v.y, mm.y, a);
+        b = fma(v.x, v.x, b);  b = fma(v.y, v.y, b);
+    }
+    block_reduce2<256>(a, b, sh);
+    if (threadIdx.x == 0) {
+        if (dot) dot[blockIdx.x] = a;
+        if (sq) sq[blockIdx.x] = b;
+    }
+}
+
+hipError_t launch_row_dots(hipStream_t s, const double* V, int64_t ld, int64_t nrows,
+                           int64_t ncols, const double* m, double* dot, double* sq) {
+    if (nrows <= 0) return hipSuccess;
+    if (ncols % 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(row_dots_kernel, dim3((unsigned)nrows), dim3(256), 0, s, V, ld, ncols, m, dot, sq);
+    return hipGetLastError();
+}
+
+// ---- LML pieces: sum log L_ii and m^T m ---------------------------------------
+// reference: tune_hyperparms_regression.py:312 (np.log(np.diagonal(L)).sum(0) and
+// y^T alpha = m^T m)
+__global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* A, int64_t ld,
+                                                           const double* m, int64_t n, double* out2) {
+    __shared__ double sh[32];
+    double a = 0., b = 0.;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        a += log(A[i * (ld + 1)]);
+        const double mi = m[i];
+        b = fma(mi, mi, b);
+    }
+    block_reduce2<1024>(a, b, sh);
+    if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
+}
+
+hipError_t launch_lml_reduce(hipStream_t s, const double* A, int64_t ld, const double* m,
+                             int64_t n, double* out2) {
+    hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, s, A, ld, m, n, out2);
+    return hipGetLastError();
+}
+
+// ---- backward substitution L^T x = b (reference: GP_regression.py:140) --------
+// Blocks of 64 unknowns from the bottom up.  diag kernel: one wavefront solves
+// L_jj^T x_j = b_j column-oriented (x_r known -> b_c -= L[r][c] * x_r, c < r);
+// update kernel: b[c] -= sum_r L[j0 + r][c] * x_j[r] for all c < j0, one thread
+// per column (coalesced along the rows of L).
+__global__ __launch_bounds__(64) void trsv_lt_diag_kernel(const double* L, int64_t ld, double* b,
+                                                           int64_t j0) {
+    const int lane = threadIdx.x;
+    const double* Ljj = L + j0 * ld + j0;
+    double bc = b[j0 + lane];
+    for (int r = 63; r >= 0; --r) {
+        const double lrc = (lane <= r) ? Ljj[(int64_t)r * ld + lane] : 0.0;  // row r, coalesced
+        // x_r = b_r / L[r][r], computed by lane r and broadcast
+        const double xr_local = bc / lrc;          // meaningful on lane r only
+        int lo = __double2loint(xr_local), hi = __double2hiint(xr_local);
+        lo = __builtin_amdgcn_readlane(lo, r);
+        hi = __builtin_amdgcn_readlane(hi, r);
+        const double xr = __hiloint2double(hi, lo);
+        if (lane == r) bc = xr;
+        else if (lane < r) bc = fma(-lrc, xr, bc);
+    }
+    b[j0 + lane] = bc;
+}
+
+__global__ __launch_bounds__(256) void trsv_lt_update_kernel(const double* L, int64_t ld, double* b,
+                                                              int64_t j0) {
+    __shared__ double xs[64];
+    if (threadIdx.x < 64) xs[threadIdx.x] = b[j0 + threadIdx.x];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= j0) return;
+    const double* col = L + j0 * ld + c;
+    double s = b[c];
+#pragma unroll 8
+    for (int r = 0; r < 64; ++r) s = fma(-col[(int64_t)r * ld], xs[r], s);
+    b[c] = s;
+}
+
+hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b, int64_t n) {
+    if (n % 64) return hipErrorInvalidValue;
+    for (int64_t j0 = n - 64; j0 >= 0; j0 -= 64) {
+        hipLaunchKernelGGL(trsv_lt_diag_kernel, dim3(1), dim3(64), 0, s, L, ld, b, j0);
+        if (j0 > 0) {
+            const unsigned blocks = (unsigned)((j0 + 255) / 256);
+            hipLaunchKernelGGL(trsv_lt_update_kernel, dim3(blocks), dim3(256), 0, s, L, ld, b, j0);
+        }
+    }
+    return hipGetLastError();
+}
+
+// ---- fills / extraction --------------------------------------------------------
+__global__ void fill_rows_kernel(double* A, int64_t ld, int64_t ncols, double value) {
+    double* row = A + (int64_t)blockIdx.y * ld;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ncols;
+         j += (int64_t)gridDim.x * blockDim.x)
+        row[j] = value;
+}
+
+hipError_t launch_fill_rows(hipStream_t s, double* A, int64_t ld, int64_t nrows, int64_t ncols,
+                            double value) {
+    if (nrows <= 0 || ncols <= 0) return hipSuccess;
+    unsigned gx = (unsigned)((ncols + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(fill_rows_kernel, dim3(gx, (unsigned)nrows), dim3(256), 0, s, A, ld, ncols, value);
+    return hipGetLastError();
+}
+
+// the y row of the augmented factorisation: row[j] = y[j] (j < N), 0 beyond
+__global__ void set_yrow_kernel(double* row, const double* y, int64_t N, int64_t ncols) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < ncols) row[j] = (j < N) ? y[j] : 0.0;
+}
+
+hipError_t launch_set_yrow(hipStream_t s, double* row, const double* y, int64_t N, int64_t ncols) {
+    hipLaunchKernelGGL(set_yrow_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, row, y, N, ncols);
+    return hipGetLastError();
+}
+
+// out (r1-r0) x (c1-c0) dense <- A[r0:r1, c0:c1], zeros above the diagonal if lower_only
+__global__ void extract_kernel(const double* A, int64_t ld, int64_t r0, int64_t c0, int64_t nr,
+                               int64_t nc, double* out, int lower_only) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= nc) return;
+    const int64_t gr = r0 + i, gc = c0 + j;
+    out[i * nc + j] = (lower_only && gc > gr) ? 0.0 : A[gr * ld + gc];
+}
+
+hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0, int64_t r1,
+                          int64_t c0, int64_t c1, double* out, int lower_only) {
+    const int64_t nr = r1 - r0, nc = c1 - c0;
+    if (nr <= 0 || nc <= 0) return hipSuccess;
+    hipLaunchKernelGGL(extract_kernel, dim3((unsigned)((nc + 255) / 256), (unsigned)nr), dim3(256), 0, s,
+                       A, ld, r0, c0, nr, nc, out, lower_only);
+    return hipGetLastError();
+}
+
+// ---- probes ----------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void probe_mfma_kernel(double* sink, int iters) {
+    d4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = d4{0., 0., 0., 0.};
+    double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 + threadIdx.x * 2e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0.;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456) sink[0] = s;   // keep the loop alive
+}
+
+hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks) {
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void probe_write_kernel(double* buf, int64_t n2) {
+    d2* p = reinterpret_cast<d2*>(buf);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256)
+        p[i] = d2{1.0, 2.0};
+}
+
+hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles) {
+    hipLaunchKernelGGL(probe_write_kernel, dim3(2048), dim3(256), 0, s, buf, n_doubles / 2);
+    return hipGetLastError();
+}
+
+}  // namespace gpmi

@@ -1,0 +1,170 @@
+"""Host-side handle on one MI355X: NumPy in / NumPy out over the C-ABI.
+
+`GPContext` is the object the drop-in modules (GP_regression.py,
+tune_hyperparms_regression.py of this package) funnel through.  It owns a
+`gpmi_ctx` (one GPU, its stream and its HBM workspaces); every array crossing
+the boundary is a caller-owned float64 C-contiguous NumPy buffer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib
+from ._lib import as_f64, check, ptr, scalar
+
+
+class GPContext:
+    """One GPU.  Not thread-safe: use one per thread."""
+
+    def __init__(self, device=0):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        check(self._lib.gpmi_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.N = self.d = self.n = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpmi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- options / introspection -------------------------------------------------
+    def set_option(self, name, value):
+        check(self._lib.gpmi_set_option(self._h, name.encode(), int(value)))
+
+    def timers(self):
+        buf = np.zeros(_lib.T_COUNT)
+        check(self._lib.gpmi_get_timers(self._h, ptr(buf), _lib.T_COUNT))
+        return {k: float(buf[i]) for i, k in enumerate(_lib.TIMER_NAMES)}
+
+    def probe_mfma_f64(self):
+        v = C.c_double()
+        check(self._lib.gpmi_probe_mfma_f64(self._h, C.byref(v)))
+        return v.value
+
+    def probe_hbm_write(self, nbytes=1 << 30):
+        v = C.c_double()
+        check(self._lib.gpmi_probe_hbm_write(self._h, int(nbytes), C.byref(v)))
+        return v.value
+
+    # ---- a1: RBF_kernel -------------------------------------------------------------
+    def rbf(self, a, b, sigma, l):
+        a = as_f64(a, 2, "a")
+        b = as_f64(b, 2, "b")
+        if a.shape[1] != b.shape[1]:
+            raise ValueError("a and b must have the same number of columns (d): %s vs %s"
+                             % (a.shape, b.shape))
+        out = np.empty((a.shape[0], b.shape[0]), dtype=np.float64)
+        check(self._lib.gpmi_rbf(self._h, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
+                                 scalar(sigma, "sigma"), scalar(l, "l"), ptr(out)))
+        return out
+
+    # ---- fit --------------------------------------------------------------------------
+    def set_train(self, X, y):
+        X = as_f64(X, 2, "X_train")
+        y = as_f64(y, None, "y_train").reshape(-1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError("X_train has %d rows but y_train has %d entries" % (X.shape[0], y.shape[0]))
+        check(self._lib.gpmi_set_train(self._h, ptr(X), X.shape[0], X.shape[1], ptr(y)))
+        self.N, self.d = X.shape
+
+    def factorize(self, sigma, l, noise_var):
+        """K + s I -> L, m = L^-1 y; returns the log-marginal-likelihood."""
+        lml = C.c_double()
+        bad = C.c_int64()
+        st = self._lib.gpmi_factorize(self._h, scalar(sigma, "sigma"), scalar(l, "l"),
+                                      scalar(noise_var, "noise_var"), C.byref(lml), C.byref(bad))
+        check(st, bad.value)
+        return lml.value
+
+    def fit(self, X, y, sigma, l, noise_var):
+        self.set_train(X, y)
+        return self.factorize(sigma, l, noise_var)
+
+    def alpha(self):
+        out = np.empty(self.N)
+        check(self._lib.gpmi_get_alpha(self._h, ptr(out)))
+        return out
+
+    def m(self):
+        out = np.empty(self.N)
+        check(self._lib.gpmi_get_m(self._h, ptr(out)))
+        return out
+
+    def diag(self):
+        out = np.empty(self.N)
+        check(self._lib.gpmi_get_diag(self._h, ptr(out)))
+        return out
+
+    def factor(self, r0=0, r1=None, c0=0, c1=None):
+        r1 = self.N if r1 is None else r1
+        c1 = self.N if c1 is None else c1
+        out = np.empty((r1 - r0, c1 - c0))
+        check(self._lib.gpmi_get_factor_block(self._h, r0, r1, c0, c1, ptr(out)))
+        return out
+
+    # ---- predict ----------------------------------------------------------------------
+    def set_test(self, Xs):
+        Xs = as_f64(Xs, 2, "X_test")
+        if Xs.shape[1] != self.d:
+            raise ValueError("X_test has d=%d but the training set has d=%d" % (Xs.shape[1], self.d))
+        check(self._lib.gpmi_set_test(self._h, ptr(Xs), Xs.shape[0]))
+        self.n = Xs.shape[0]
+
+    def predict_resident(self, want_sd=True):
+        mu = np.empty(self.n)
+        o2 = np.empty(self.n)
+        check(self._lib.gpmi_predict_resident(self._h, ptr(mu), ptr(o2), 1 if want_sd else 0))
+        return mu, o2
+
+    def predict(self, Xs, want_sd=True):
+        self.set_test(Xs)
+        return self.predict_resident(want_sd)
+
+    def post_chol(self, jitter):
+        out = np.empty((self.n, self.n))
+        bad = C.c_int64()
+        st = self._lib.gpmi_post_chol(self._h, float(jitter), ptr(out), C.byref(bad))
+        check(st, bad.value)
+        return out
+
+    # ---- batched LML ----------------------------------------------------------------
+    def lml_batch(self, triples):
+        """triples: (T,3) = (l, sigma_f, noise_var) rows.  Returns (lml[T], status[T])."""
+        t = as_f64(triples, 2, "triples")
+        if t.shape[1] != 3:
+            raise ValueError("triples must be (T, 3) = (l, sigma_f, noise_var)")
+        out = np.empty(t.shape[0])
+        status = np.zeros(t.shape[0], dtype=np.int32)
+        check(self._lib.gpmi_lml_batch(self._h, ptr(t), t.shape[0], ptr(out),
+                                       status.ctypes.data_as(C.POINTER(C.c_int))))
+        return out, status
+
+
+_tls = threading.local()
+
+
+def default_context():
+    """Per-thread lazily created context on GPMI_DEVICE (default GPU 0)."""
+    import os
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None or ctx._h is None:
+        ctx = GPContext(int(os.environ.get("GPMI_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        _tls.ctx = ctx
+    return ctx

@@ -1,0 +1,176 @@
+/*
+ * gpmi.h -- C-ABI of libgpmi355x.so, the MI355X (gfx950) implementation of the
+ * GP-regression hot path of happyjin/Gaussian_process.
+ *
+ * The reference has no FFI/plugin interface: its boundary is a set of plain
+ * Python functions other scripts import.  Each entry point
+ * below names the reference statement(s) it replaces; the Python shim in
+ * gaussian_process_amd/ binds them with ctypes and keeps the reference's
+ * function signatures.  All matrices are float64, row-major, caller-owned host
+ * buffers unless the name says `_dev` (device pointers for the multi-GPU
+ * driver).  No torch types cross this boundary.
+ *
+ * Every function returns an int status:
+ *   GPMI_OK            0
+ *   GPMI_ERR_NOT_PD    1  Cholesky met a non-positive pivot (reference:
+ *                         numpy.linalg.LinAlgError from np.linalg.cholesky,
+ *                         GP_regression.py:138,154); *bad_pivot = 1-based index
+ *   GPMI_ERR_BAD_ARG   2  -> ValueError in the shim
+ *   GPMI_ERR_RUNTIME   3  HIP runtime failure -> RuntimeError; text in
+ *                         gpmi_last_error()
+ * Nothing aborts the process.  A context is not thread-safe (one per thread).
+ */
+#ifndef GPMI_H
+#define GPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMI_OK 0
+#define GPMI_ERR_NOT_PD 1
+#define GPMI_ERR_BAD_ARG 2
+#define GPMI_ERR_RUNTIME 3
+
+#define GPMI_ABI_VERSION 1
+
+/* stage timer slots filled by gpmi_get_timers (milliseconds, hipEvent-timed on
+ * the context's compute stream; 0 when the stage did not run in the last call) */
+enum {
+    GPMI_T_KBUILD = 0,    /* a1+a2: K(X,X)+s*I lower tiles                */
+    GPMI_T_CHOL = 1,      /* a3 (+a4 folded in): blocked Cholesky, total   */
+    GPMI_T_CHOL_PANEL = 2,/*    of which: diagonal block + panel TRSM      */
+    GPMI_T_CHOL_TRAIL = 3,/*    of which: trailing SYRK/GEMM updates       */
+    GPMI_T_LML = 4,       /* a10: reductions for the log-marginal-likelihood */
+    GPMI_T_KS = 5,        /* a1 for K(X*,X) (transposed K_s)               */
+    GPMI_T_SOLVE_V = 6,   /* a7: v = L^-1 K_s (TRSM sweep), total          */
+    GPMI_T_MEANVAR = 7,   /* a6+a8: mean / variance reductions             */
+    GPMI_T_ALPHA = 8,     /* a5: backward solve L^T alpha = m              */
+    GPMI_T_POSTCHOL = 9,  /* f1: v^T v, K** + jitter*I - v^T v, its Cholesky */
+    GPMI_T_TRAIL_LAUNCHES = 10, /* number of trailing-update launches in last fit */
+    GPMI_T_TRAIL_FLOPS = 11,    /* algorithmic flops of those launches (2*M*N*K over computed tiles) */
+    GPMI_T_COUNT = 16
+};
+
+typedef struct gpmi_ctx gpmi_ctx;
+
+int gpmi_abi_version(void);
+/* text of the last GPMI_ERR_RUNTIME / GPMI_ERR_BAD_ARG on this thread */
+const char* gpmi_last_error(void);
+int gpmi_device_count(int* count);
+
+/* one context = one GPU (device ordinal) + its streams and workspaces */
+int gpmi_ctx_create(int device, gpmi_ctx** out);
+int gpmi_ctx_destroy(gpmi_ctx* ctx);
+/* tuning knobs (block sizes etc.); unknown names -> GPMI_ERR_BAD_ARG */
+int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);
+
+/* RBF_kernel(a, b, sigma, l)                         GP_regression.py:8-19
+ *   out[i*M + j] = sigma^2 * exp(-.5 * (1/l^2) * sum_k (a[i,k]-b[j,k])^2)
+ * a: N x d, b: M x d, out: N x M. */
+int gpmi_rbf(gpmi_ctx* ctx, const double* a, int64_t N, const double* b, int64_t M,
+             int64_t d, double sigma, double ell, double* out);
+
+/* Copy the training set to the device (X: N x d, y: N).  Replaces nothing in
+ * the reference (it has no device); separates PCIe from the timed path. */
+int gpmi_set_train(gpmi_ctx* ctx, const double* X, int64_t N, int64_t d, const double* y);
+
+/* K = RBF_kernel(X,X,sigma,l); L = cholesky(K + s*I); m = solve(L, y)
+ *                    GP_regression.py:126,138-139; tune_hyperparms_regression.py:306-308
+ * and the log-marginal-likelihood of tune_hyperparms_regression.py:312:
+ *   lml = -.5*y^T alpha - sum(log(diag L)) - N/2*log(2*pi)   (y^T alpha = m^T m)
+ * Leaves L and m resident in the context.  lml/bad_pivot may be NULL. */
+int gpmi_factorize(gpmi_ctx* ctx, double sigma, double ell, double noise_var,
+                   double* lml, int64_t* bad_pivot);
+
+/* gpmi_set_train + gpmi_factorize in one call (host buffers in). */
+int gpmi_fit(gpmi_ctx* ctx, const double* X, int64_t N, int64_t d, const double* y,
+             double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot);
+
+/* alpha = solve(L.T, m)                               GP_regression.py:140
+ * out: N doubles. */
+int gpmi_get_alpha(gpmi_ctx* ctx, double* alpha_out);
+/* m = solve(L, y) (GP_regression.py:139) and diag(L); each N doubles. */
+int gpmi_get_m(gpmi_ctx* ctx, double* m_out);
+int gpmi_get_diag(gpmi_ctx* ctx, double* diag_out);
+/* rows [r0,r1) x cols [c0,c1) of the resident factor, lower part, zeros above
+ * the diagonal (np.linalg.cholesky convention); for tests and small N. */
+int gpmi_get_factor_block(gpmi_ctx* ctx, int64_t r0, int64_t r1, int64_t c0, int64_t c1,
+                          double* out);
+
+/* Copy test inputs to the device (Xs: n x d, d as in set_train). */
+int gpmi_set_test(gpmi_ctx* ctx, const double* Xs, int64_t n);
+
+/* K_s = RBF_kernel(X, Xs); mu = K_s.T @ alpha; v = solve(L, K_s);
+ * var = diag(K_ss) - sum(v**2, 0); sd = sqrt(var)     GP_regression.py:127,143-148
+ * mu, out2: n doubles each; out2 = sd if want_sd else var.  A negative var
+ * gives NaN sd, as np.sqrt does in the reference (no clamp).  Either output
+ * may be NULL.  v stays resident (transposed, n x N) for gpmi_post_chol. */
+int gpmi_predict_resident(gpmi_ctx* ctx, double* mu, double* out2, int want_sd);
+int gpmi_predict(gpmi_ctx* ctx, const double* Xs, int64_t n, double* mu, double* out2,
+                 int want_sd);
+
+/* L_ = cholesky(K_ss + jitter*I - v.T @ v)            GP_regression.py:154
+ * for the test set of the last predict; L_out: n x n row-major, zeros above the
+ * diagonal.   */
+int gpmi_post_chol(gpmi_ctx* ctx, double jitter, double* L_out, int64_t* bad_pivot);
+
+/* compute_mar_likelihood for T hyper-parameter triples on one training set
+ *                    tune_hyperparms_regression.py:292-313 called in the loops at :368-369,:385-386
+ * triples: T x 3 = (ell, sigma_f, noise_var).  lml_out: T doubles (NaN where the
+ * factorisation failed), status_out: T ints (GPMI_OK / GPMI_ERR_NOT_PD), may be
+ * NULL.  Uses the training set of gpmi_set_train. */
+int gpmi_lml_batch(gpmi_ctx* ctx, const double* triples, int64_t T, double* lml_out,
+                   int* status_out);
+
+int gpmi_get_timers(gpmi_ctx* ctx, double* stage_ms, int count);
+/* block the host until everything queued on the context has finished */
+int gpmi_sync(gpmi_ctx* ctx);
+
+/* ---- micro-benchmarks used by bench.py to re-read chip peaks on the box ---- */
+/* fp64 MFMA issue rate: returns achieved TFLOP/s of a register-only
+ * v_mfma_f64_16x16x4_f64 loop over the whole chip. */
+int gpmi_probe_mfma_f64(gpmi_ctx* ctx, double* tflops);
+/* streaming-store bandwidth (GB/s) over `bytes` of device memory */
+int gpmi_probe_hbm_write(gpmi_ctx* ctx, int64_t bytes, double* gbps);
+
+/* ---------------------------------------------------------------------------
+ * Device-pointer block primitives for the multi-GPU (row-block cyclic) driver
+ * in gaussian_process_amd/dist.py.  `stream` is a hipStream_t passed as void*
+ * (torch.cuda.current_stream().cuda_stream).  All leading dimensions in
+ * doubles.  Sizes must be multiples of 64 (panel width) / 128 (rows).
+ * ------------------------------------------------------------------------- */
+/* rows [row0,row0+nrows) of K(X,X)+s*I, columns [0, row0+nrows), into out
+ * (nrows x ld); columns beyond N and rows beyond N are the identity padding. */
+int gpmi_dev_rbf_rows(void* stream, const double* X_dev, int64_t N, int64_t d,
+                      int64_t row0, int64_t nrows, int64_t ncols, double sigma, double ell,
+                      double noise_var, double* out_dev, int64_t ld);
+/* rows [row0,row0+nrows) of K(Xs,X): out[i][j] = k(Xs[row0+i], X[j]), j < ncols */
+int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const double* X_dev,
+                       int64_t N, int64_t d, int64_t row0, int64_t nrows, int64_t ncols,
+                       double sigma, double ell, double* out_dev, int64_t ld);
+/* in-place Cholesky of the nb x nb diagonal block (nb multiple of 64);
+ * info_dev: int64 on the device, atomically min-ed with col_offset + failing
+ * column (initialise to INT64_MAX). */
+int gpmi_dev_potrf_block(void* stream, double* A_dev, int64_t ld, int64_t nb,
+                         int64_t col_offset, int64_t* info_dev);
+/* X (m x nb, ldx) <- X * L^-T with L the nb x nb lower factor (ldl) */
+int gpmi_dev_trsm_block(void* stream, const double* L_dev, int64_t ldl, double* X_dev,
+                        int64_t ldx, int64_t m, int64_t nb);
+/* C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T.  lower != 0: only tiles
+ * that intersect {col <= row + diag_off} are touched. */
+int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                     const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                     int lower, int64_t diag_off);
+/* out[i] = sum_j V[i][j]*m[j] ; out2[i] = sum_j V[i][j]^2  (partial sums over
+ * the columns this rank owns), i < nrows, j < ncols */
+int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows,
+                      int64_t ncols, const double* m_dev, double* dot_out_dev,
+                      double* sq_out_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMI_H */

@@ -1,0 +1,158 @@
+"""CPU oracle for the GP-regression hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+This module is a NumPy restatement of the reference's algorithm for the path
+named in BASELINE.json (`north_star`): squared-exponential kernel matrix,
+K + s*I, Cholesky, the two solves for alpha, predictive mean / variance and the
+log-marginal-likelihood.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import it; the product package
+`gaussian_process_amd` never does (it fails loudly when the HIP library is
+missing instead of falling back to this file).
+
+Every function cites the reference lines it follows (paths are relative to
+/root/reference, which does not exist on the GPU box; nothing here reads it).
+
+Pinning: the reference ships no tests or golden vectors, so the
+oracle is pinned against outputs of the reference ITSELF, generated in the
+build container by `oracle/make_golden.py` (which imports
+/root/reference/GP_regression.py) and committed under `tests/golden/`.
+`tests/test_oracle_vs_golden.py` checks this file against those vectors.
+`compute_mar_likelihood` / `bayesian_opt` live in a Python-2-only file that
+cannot be imported; they are restated line by line and pinned through the
+imported `RBF_kernel` + the same LAPACK calls (see make_golden.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# Constants hard-coded inside the reference's function bodies.
+NOISE_VAR = 0.0005        # GP_regression.py:120, tune_hyperparms_regression.py:302
+SIGMA_F = 1               # GP_regression.py:121
+POST_JITTER = 1e-6        # GP_regression.py:154
+BO_NOISE_VAR = 0.0001     # tune_hyperparms_regression.py:75
+
+
+def RBF_kernel(a, b, sigma, l):
+    """GP_regression.py:8-19 -- broadcast (N,d,M) difference, square, sum over
+    axis 1 (sequential in k), then sigma**2 * exp(-.5 * (1/l**2) * sqdist)."""
+    sqdist = ((a[:, :, None] - b[:, :, None].T) ** 2).sum(1)
+    return (sigma ** 2) * np.exp(-.5 * (1 / (l ** 2)) * sqdist)
+
+
+def RBF_kernel_chunked(a, b, sigma, l, rows=256):
+    """Same per-element arithmetic as GP_regression.py:18-19 but row-chunked so
+    the (N,d,M) temporary stays small (memory-feasible variant)."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    out = np.empty((a.shape[0], b.shape[0]), dtype=np.float64)
+    bt = b[:, :, None].T
+    for r0 in range(0, a.shape[0], rows):
+        blk = a[r0:r0 + rows]
+        sq = ((blk[:, :, None] - bt) ** 2).sum(1)
+        out[r0:r0 + rows] = (sigma ** 2) * np.exp(-.5 * (1 / (l ** 2)) * sq)
+    return out
+
+
+def dataset_generator(N, n):
+    """GP_regression.py:53-68 -- consumes np.random's global state in the order
+    uniform(N,1) then randn(N)."""
+    s = 0.0005
+    f = lambda x: np.sin(0.9 * x).flatten()
+    X_train = np.random.uniform(-5, 5, size=(N, 1))
+    y_train = f(X_train) + np.sqrt(s) * np.random.randn(N)
+    X_test = np.linspace(-5, 5, n).reshape(-1, 1)
+    return f, X_train, y_train, X_test
+
+
+def posterior(X_train, X_test, y_train, sigma, l, s):
+    """GP_regression.py:126-148 with free (sigma, s): returns every intermediate
+    the parity tests compare (L, m, alpha, mu, v, var)."""
+    N = len(X_train)
+    K_train = RBF_kernel(X_train, X_train, sigma, l)             # :126
+    K_s = RBF_kernel(X_train, X_test, sigma, l)                  # :127
+    K_ss = RBF_kernel(X_test, X_test, sigma, l)                  # :128
+    L = np.linalg.cholesky(K_train + s * np.eye(N))              # :138
+    m = np.linalg.solve(L, y_train)                              # :139
+    alpha = np.linalg.solve(L.T, m)                              # :140
+    mu_post = np.dot(K_s.T, alpha)                               # :143
+    v = np.linalg.solve(L, K_s)                                  # :144
+    var_test = np.diag(K_ss) - np.sum(v ** 2, axis=0)            # :147
+    return dict(K=K_train, K_s=K_s, K_ss=K_ss, L=L, m=m, alpha=alpha,
+                mu=mu_post, v=v, var=var_test)
+
+
+def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun):
+    """GP_regression.py:109-156 (rbf branch only; 'lin'/'per' are out of scope,
+    SURVEY.md section 2 row 4).  Draws np.random.normal((n, num_fun)) once (:155)."""
+    if kernel_choice != 'rbf':
+        raise NotImplementedError("oracle restates the 'rbf' branch only")
+    s = NOISE_VAR
+    sigma = SIGMA_F
+    n = len(X_test)
+    p = posterior(X_train, X_test, y_train, sigma, l, s)
+    with np.errstate(invalid='ignore'):
+        stand_devi = np.sqrt(p['var'])                           # :148
+    L_ = np.linalg.cholesky(p['K_ss'] + POST_JITTER * np.eye(n)
+                            - np.dot(p['v'].T, p['v']))          # :154
+    f_post_fun = p['mu'].reshape(-1, 1) + np.dot(
+        L_, np.random.normal(size=(n, num_fun)))                 # :155
+    return p['mu'], stand_devi, f_post_fun
+
+
+def compute_mar_likelihood(X_train, X_test, y_train, sigma, l, s=NOISE_VAR):
+    """tune_hyperparms_regression.py:292-313.  X_test is accepted and unused, as
+    in the reference.  `s` defaults to the hard-coded 0.0005 (:302)."""
+    n = len(X_train)                                             # :303
+    K_train = RBF_kernel(X_train, X_train, sigma, l)             # :306
+    L = np.linalg.cholesky(K_train + s * np.eye(n))              # :307
+    m = np.linalg.solve(L, y_train)                              # :308
+    alpha = np.linalg.solve(L.T, m)                              # :309
+    return (-.5 * np.dot(y_train.T, alpha)
+            - np.log(np.diagonal(L)).sum(0)
+            - n / 2.0 * np.log(2 * np.pi))                       # :312
+
+
+def bayesian_opt(X_train, X_test, y_train):
+    """tune_hyperparms_regression.py:67-101: the same posterior with s=1e-4,
+    sigma=l=1, num_fun=1."""
+    s = BO_NOISE_VAR
+    n = len(X_test)
+    p = posterior(X_train, X_test, y_train, 1, 1, s)
+    with np.errstate(invalid='ignore'):
+        stand_devi = np.sqrt(p['var'])                           # :95
+    L_ = np.linalg.cholesky(p['K_ss'] + 1e-6 * np.eye(n)
+                            - np.dot(p['v'].T, p['v']))          # :98
+    f_post_fun = p['mu'].reshape(-1, 1) + np.dot(
+        L_, np.random.normal(size=(n, 1)))                       # :99
+    return p['mu'], stand_devi, f_post_fun
+
+
+# ---------------------------------------------------------------------------
+# Memory-feasible restatement: identical K arithmetic, but true
+# triangular solves instead of LU on a triangular matrix.  Used as the CPU
+# baseline at sizes where the (N,d,N) broadcast does not fit, and as the
+# checker at mid sizes (N of a few thousand) where LU would take minutes.
+# ---------------------------------------------------------------------------
+def fit_predict_feasible(X_train, X_test, y_train, sigma, l, s, rows=256):
+    import scipy.linalg as sla
+    N = len(X_train)
+    K = RBF_kernel_chunked(X_train, X_train, sigma, l, rows)
+    K[np.diag_indices(N)] += s
+    L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    m = sla.solve_triangular(L, y_train, lower=True, check_finite=False)
+    alpha = sla.solve_triangular(L, m, lower=True, trans='T', check_finite=False)
+    K_s = RBF_kernel_chunked(X_train, X_test, sigma, l, rows)
+    mu = K_s.T @ alpha
+    v = sla.solve_triangular(L, K_s, lower=True, overwrite_b=True, check_finite=False)
+    var = sigma ** 2 - np.einsum('ij,ij->j', v, v)
+    lml = (-.5 * float(y_train @ alpha) - float(np.log(np.diagonal(L)).sum())
+           - N / 2.0 * np.log(2 * np.pi))
+    return dict(mu=mu, var=var, alpha=alpha, m=m, lml=lml, diagL=np.diagonal(L).copy())
+
+
+def synthetic_problem(N, d, n, seed=20240531):
+    """SURVEY.md section 8(d) synthetic inputs (the bench / parity workload)."""
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(-1, 1, (N, d))
+    y = np.sin(0.9 * X.sum(1)) + np.sqrt(5e-4) * rng.standard_normal(N)
+    Xs = rng.uniform(-1, 1, (n, d))
+    return X, y, Xs

@@ -1,0 +1,124 @@
+"""Generate tests/golden/*.npz from the reference itself.  TEST INFRASTRUCTURE.
+
+Runs ONLY in the build container (needs /root/reference); the GPU box never
+sees the reference, it gets the committed .npz fixtures.  The fixtures hold
+data only -- inputs and the reference's outputs on them.
+
+What is imported:  /root/reference/GP_regression.py  (Python 3 clean).
+What cannot be:    tune_hyperparms_regression.py is Python-2 syntax
+                   (first SyntaxError at :150), so the LML goldens are produced
+                   by issuing its lines :306-312 here, with the IMPORTED
+                   RBF_kernel and the same np.linalg calls.
+
+usage:  MPLBACKEND=Agg python oracle/make_golden.py
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.path.insert(0, "/root/reference")
+
+import numpy as np  # noqa: E402
+import GP_regression as REF  # noqa: E402  (the reference)
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def ref_lml(X, y, sigma, l, s=0.0005):
+    # tune_hyperparms_regression.py:303-312 issued with the imported RBF_kernel
+    n = len(X)
+    K = REF.RBF_kernel(X, X, sigma, l)
+    L = np.linalg.cholesky(K + s * np.eye(n))
+    m = np.linalg.solve(L, y)
+    alpha = np.linalg.solve(L.T, m)
+    lml = -.5 * np.dot(y.T, alpha) - np.log(np.diagonal(L)).sum(0) - n / 2.0 * np.log(2 * np.pi)
+    return lml, L, m, alpha
+
+
+def k_summary(K):
+    return dict(K_corner=K[:16, :16].copy(), K_rowsum=K.sum(1), K_fro=np.linalg.norm(K),
+                K_lastrow=K[-1].copy())
+
+
+def cfg1(seed):
+    """BASELINE config 1: GP_regression.py defaults at N=512, n=100, d=1, l=1."""
+    np.random.seed(seed)
+    f, X, y, Xs = REF.dataset_generator(512, 100)
+    state_after_data = np.random.get_state()
+    mu, sd, fpost = REF.prediction(X, Xs, y, 'rbf', 1, 10)
+    np.random.set_state(state_after_data)
+    normals = np.random.normal(size=(100, 10))      # the draw prediction() made (:155)
+    K = REF.RBF_kernel(X, X, 1, 1)
+    lml, L, m, alpha = ref_lml(X, y, 1, 1)
+    np.savez_compressed(os.path.join(OUT, "cfg1_seed%d.npz" % seed), seed=seed, X=X, y=y, Xs=Xs,
+                        mu=mu, sd=sd, f_post=fpost, normals=normals, lml=lml, diagL=np.diagonal(L),
+                        m=m, alpha=alpha, ell=1.0, sigma=1.0, s=0.0005, **k_summary(K))
+
+
+def dcase(name, N, d, n, lo, hi, ell, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.uniform(lo, hi, (N, d))
+    y = np.sin(0.9 * X.sum(1)) + np.sqrt(5e-4) * rng.standard_normal(N)
+    Xs = rng.uniform(lo, hi, (n, d))
+    np.random.seed(seed)
+    mu, sd, fpost = REF.prediction(X, Xs, y, 'rbf', ell, 3)
+    np.random.seed(seed)
+    normals = np.random.normal(size=(n, 3))
+    K = REF.RBF_kernel(X, X, 1, ell)
+    Ks = REF.RBF_kernel(X, Xs, 1, ell)
+    lml, L, m, alpha = ref_lml(X, y, 1, ell)
+    # a second hyper-parameter triple through the LML formula (sigma != 1)
+    lml2, _, _, _ = ref_lml(X, y, 1.5, 0.75 * ell)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, X=X, y=y, Xs=Xs, mu=mu, sd=sd,
+                        f_post=fpost, normals=normals, lml=lml, lml2=lml2, sigma2=1.5, ell2=0.75 * ell,
+                        diagL=np.diagonal(L), m=m, alpha=alpha, ell=float(ell), sigma=1.0, s=0.0005,
+                        Ks_corner=Ks[:16, :16].copy(), Ks_colsum=Ks.sum(0), **k_summary(K))
+
+
+def edge_cases():
+    out = {}
+    # N=1, n=1
+    X = np.array([[0.3]]); y = np.array([0.7]); Xs = np.array([[0.1]])
+    np.random.seed(5)
+    mu, sd, fp = REF.prediction(X, Xs, y, 'rbf', 1, 2)
+    out.update(n1_X=X, n1_y=y, n1_Xs=Xs, n1_mu=mu, n1_sd=sd, n1_fpost=fp,
+               n1_lml=ref_lml(X, y, 1, 1)[0])
+    # duplicate rows: K exactly singular, rescued by + s I
+    rng = np.random.default_rng(11)
+    Xd = rng.uniform(-2, 2, (24, 3)); Xd[7] = Xd[3]; Xd[20] = Xd[3]
+    yd = np.sin(Xd.sum(1)); Xsd = rng.uniform(-2, 2, (9, 3))
+    np.random.seed(6)
+    mu, sd, fp = REF.prediction(Xd, Xsd, yd, 'rbf', 1.5, 1)
+    out.update(dup_X=Xd, dup_y=yd, dup_Xs=Xsd, dup_mu=mu, dup_sd=sd, dup_fpost=fp,
+               dup_lml=ref_lml(Xd, yd, 1, 1.5)[0], dup_ell=1.5)
+    # ragged (non tile-multiple) sizes, n > N
+    Xr = rng.uniform(-1, 1, (77, 5)); yr = np.cos(Xr[:, 0]) + 0.1 * Xr[:, 1]; Xsr = rng.uniform(-1, 1, (131, 5))
+    np.random.seed(7)
+    mu, sd, fp = REF.prediction(Xr, Xsr, yr, 'rbf', 0.9, 2)
+    out.update(rag_X=Xr, rag_y=yr, rag_Xs=Xsr, rag_mu=mu, rag_sd=sd, rag_fpost=fp,
+               rag_lml=ref_lml(Xr, yr, 1, 0.9)[0], rag_ell=0.9)
+    # RBF_kernel alone on rectangular / scalar-as-array hyper-parameters (l[i] at tune...:369)
+    A = rng.normal(size=(33, 4)); B = rng.normal(size=(65, 4))
+    out.update(rbf_A=A, rbf_B=B, rbf_K=REF.RBF_kernel(A, B, 1.7, np.array([0.6]))[:, :],
+               rbf_sigma=1.7, rbf_ell=0.6)
+    # non-PD: negative "noise" big enough to break Cholesky -> LinAlgError in the reference
+    Xn = rng.uniform(-1, 1, (40, 2)); Kn = REF.RBF_kernel(Xn, Xn, 1, 2.0)
+    try:
+        np.linalg.cholesky(Kn - 0.5 * np.eye(40))
+        raised = 0
+    except np.linalg.LinAlgError:
+        raised = 1
+    out.update(npd_X=Xn, npd_ell=2.0, npd_shift=-0.5, npd_raised=raised)
+    np.savez_compressed(os.path.join(OUT, "edge_cases.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    for sd_ in (0, 1, 2):
+        cfg1(sd_)
+    for N in (64, 256, 1024):
+        dcase("d8_box1_N%d" % N, N, 8, 48, -1.0, 1.0, 2.0, 100 + N)
+        dcase("d8_box5_N%d" % N, N, 8, 48, -5.0, 5.0, 4.0, 200 + N)
+    dcase("d16_box1_N384", 384, 16, 40, -1.0, 1.0, 2.8, 316)
+    edge_cases()
+    print("wrote", sorted(os.listdir(OUT)))
