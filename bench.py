@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GP fit + predict at N=65536, d=8, n=4096 test points, fp64.
+
+One "step" = the whole hot path on inputs already resident in HBM:
+  K(X,X)+s*I build -> blocked Cholesky (forward solve folded in) -> LML
+  -> K(X*,X) build -> v = L^-1 K_s sweep -> predictive mean / variance.
+value = algorithmic fp64 flops of that path (N^3/3 + N^2/2 + N/6 for the Cholesky,
+N^2*n for the triangular solve of K_s) / wall time, whole job, in TFLOP/s.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size N] [--dim d] [--ntest n]
+For --gpus > 1 launch with torch.distributed.run (one rank per GPU, RCCL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6     # vendor dense fp64 matrix peak, MI355X
+PEAK_HBM_GBPS = 8000.0
+
+
+def algorithmic_flops(N, n):
+    chol = N ** 3 / 3.0 + N ** 2 / 2.0 + N / 6.0
+    trsm = float(N) ** 2 * n
+    return chol + trsm
+
+
+def cpu_baseline(d, n_test):
+    """The oracle (a port of the reference's NumPy path with true triangular solves and a
+    C kernel-matrix build) timed on this host's cores on a bounded sample of the workload."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gp_oracle as O
+    lib = os.path.join(ROOT, "oracle", "build", "librbf_oracle.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    Ns = int(os.environ.get("GPMI_CPU_BASELINE_N", "12288"))
+    X, y, Xs = O.synthetic_problem(Ns, d, n_test)
+    t0 = time.perf_counter()
+    O.fit_predict_feasible(X, Xs, y, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
+    dt = time.perf_counter() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        th = [i.get("num_threads") for i in threadpool_info() if i.get("user_api") == "blas"]
+        if th:
+            threads = max(th)
+    except Exception:
+        pass
+    return {"value": algorithmic_flops(Ns, n_test) / dt / 1e12, "unit": "TFLOP/s", "cores": threads,
+            "kind": "port", "seconds": dt,
+            "sample": "oracle fit+predict at N=%d d=%d n=%d (same generator and hyper-parameters; "
+                      "the reference's own (N,d,N) broadcast cannot run beyond N~8192)" % (Ns, d, n_test)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=65536)
+    ap.add_argument("--dim", type=int, default=8)
+    ap.add_argument("--ntest", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    N, d, n = args.size, args.dim, args.ntest
+    ell, sigma, s = 2.0 * np.sqrt(d / 8.0), 1.0, 5e-4
+
+    rng = np.random.default_rng(20240531)
+    X = rng.uniform(-1, 1, (N, d))
+    y = np.sin(0.9 * X.sum(1)) + np.sqrt(5e-4) * rng.standard_normal(N)
+    Xs = rng.uniform(-1, 1, (n, d))
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from gaussian_process_amd.dist import DistGP
+        gp = DistGP(local_rank)
+        gp.set_train(X, y)
+        gp.set_test(Xs)
+
+        def step():
+            lml = gp.factorize(sigma, ell, s)
+            mu, var = gp.predict_resident(want_sd=False)
+            return lml, mu, var
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+        timers_fn = gp.timers
+    else:
+        from gaussian_process_amd import GPContext
+        ctx = GPContext(local_rank)
+        ctx.set_train(X, y)      # inputs resident in HBM before the timed region
+        ctx.set_test(Xs)
+
+        def step():
+            lml = ctx.factorize(sigma, ell, s)
+            mu, var = ctx.predict_resident(want_sd=False)
+            return lml, mu, var
+
+        def barrier():
+            torch.cuda.synchronize()
+        timers_fn = None
+
+    for _ in range(args.warmup):
+        step()
+    stage = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lml, mu, var = step()
+        if world == 1:
+            tf = ctx.timers()
+            for k, v in tf.items():
+                stage[k] = stage.get(k, 0.0) + v
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        stage = timers_fn()
+    ms_per_step = dt / args.steps * 1e3
+    flops = algorithmic_flops(N, n)
+    value = flops / (dt / args.steps) / 1e12
+
+    if rank == 0:
+        assert np.all(np.isfinite(mu)) and np.isfinite(lml)
+        out = {
+            "metric": "gp_fit_predict_fp64_tflops (fit+predict wall seconds in `seconds`)",
+            "value": value, "unit": "TFLOP/s", "seconds": dt / args.steps,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "GP fit+predict N=%d d=%d n_test=%d (BASELINE configs[2])" % (N, d, n),
+                       "N": N, "d": d, "n_test": n, "ell": float(ell), "sigma_f": sigma, "noise_var": s,
+                       "partition": "single GPU" if world == 1 else "row-block cyclic x%d" % world},
+            "lml": float(lml),
+        }
+        if stage:
+            k = args.steps if world == 1 else 1
+            trail_ms = stage.get("chol_trail", 0.0) / k
+            trail_flops = stage.get("trail_flops", 0.0) / k
+            launches = stage.get("trail_launches", 0.0) / k
+            ach = trail_flops / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else 0.0
+            out["roofline"] = {
+                "kernel": "gemm_nt_kernel<4> (Cholesky trailing update, fp64 MFMA 16x16x4)",
+                "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": launches,
+                "flops_per_launch": trail_flops / launches if launches else 0.0,
+                "avg_launch_ms": trail_ms / launches if launches else 0.0}
+            out["stages_ms"] = {kk: vv / k for kk, vv in stage.items() if not kk.startswith("trail_")}
+            kb = stage.get("kbuild", 0.0) / k
+            if kb > 0:
+                Np = (N + 127) // 128 * 128
+                T = Np // 128
+                kbytes = 8.0 * 128 * 128 * T * (T + 1) / 2 + 16.0 * N * d
+                out["kbuild_hbm"] = {"bound": "hbm", "achieved": kbytes / (kb * 1e-3) / 1e9,
+                                     "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                     "frac": kbytes / (kb * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                     "bytes": kbytes, "note": "lower tiles incl. diagonal"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, n)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

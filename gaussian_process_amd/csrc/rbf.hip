@@ -5,22 +5,27 @@
 //   out[i][j] = sig2 * exp(coef * sum_k (a[i,k] - b[j,k])^2)      coef = -.5*(1/l^2)
 //
 // The per-element arithmetic follows the reference exactly: difference, square
-// and a sequential (k = 0..d-1) sum with one rounding per operation (no FMA
-// contraction), one multiplication by coef, exp, one multiplication by sigma^2.
-// Only exp() itself may differ from NumPy's (both are < 1 ulp).
+// (one rounding each, no FMA contraction) and the sum over k in the order
+// NumPy's add.reduce uses for the middle axis of the reference's (N,d,M)
+// temporary (pairwise_sum: sequential for d < 8; eight interleaved partial sums
+// r[k mod 8], the tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and a sequential tail
+// for d <= 128; recursive halving above -- checked bit-for-bit against NumPy
+// 2.2.6 in tests/test_oracle_vs_golden.py), then one multiplication by coef,
+// exp, one multiplication by sigma^2.  Only exp() itself may differ from
+// NumPy's (both are < 1 ulp).
 //
 // HBM-write bound: a block produces a 128 x 128 tile; a wavefront writes whole
 // 1-KiB row segments (64 lanes x 16 B).  The x rows of both tile edges are
-// staged once in LDS (k-chunks of 16); the b values of a thread's two columns
-// live in registers, the a values are wave-wide LDS broadcasts.
+// staged once in LDS; for the common d (1..8, 16) the b values of a thread's two
+// columns live in registers and the a values are wave-wide LDS broadcasts.
 #include "gpmi_internal.h"
 
 namespace gpmi {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int RT = 128;    // tile edge
-constexpr int DK = 16;     // k-chunk held in LDS / registers
+constexpr int RT = 128;        // tile edge
+constexpr int LDS_MAXD = 32;   // largest d staged in LDS; above: rbf_naive_kernel
 
 struct RbfDev {
     const double* A;
@@ -37,11 +42,60 @@ struct RbfDev {
 };
 
 #pragma clang fp contract(off)
-template <int DC>   // DC: compile-time chunk length (1..16), 0 = runtime
-__global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
-    __shared__ __attribute__((aligned(16))) double As[RT * DK];
-    __shared__ __attribute__((aligned(16))) double Bs[RT * DK];
-    int ti, tj;
+
+// sum_k (a(k) - b(k))^2 in NumPy's pairwise order, n <= 128 (see file header)
+template <class FA, class FB>
+__device__ __forceinline__ double sq_pw_small(FA a, FB b, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int k = 0; k < n; ++k) { const double e = a(k) - b(k); res = res + e * e; }
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const double e = a(j) - b(j); r[j] = e * e; }
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double e = a(i + j) - b(i + j); r[j] = r[j] + e * e; }
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) { const double e = a(i) - b(i); res = res + e * e; }
+    return res;
+}
+
+template <int D, class FA, class FB>
+__device__ __forceinline__ double sq_pw_static(FA a, FB b) {
+    if constexpr (D < 8) {
+        double res = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { const double e = a(k) - b(k); res = res + e * e; }
+        return res;
+    } else {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const double e = a(j) - b(j); r[j] = e * e; }
+        constexpr int NB = D - (D % 8);
+#pragma unroll
+        for (int i = 8; i < NB; i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const double e = a(i + j) - b(i + j); r[j] = r[j] + e * e; }
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = NB; i < D; ++i) { const double e = a(i) - b(i); res = res + e * e; }
+        return res;
+    }
+}
+
+__device__ double sq_pw_global(const double* a, const double* b, int n) {
+    if (n <= 128) return sq_pw_small([&](int k) { return a[k]; }, [&](int k) { return b[k]; }, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return sq_pw_global(a, b, n2) + sq_pw_global(a + n2, b + n2, n - n2);
+}
+
+__device__ __forceinline__ bool rbf_map_tile(const RbfDev& p, int& ti, int& tj) {
     if (p.tri) {
         const int s = blockIdx.x;
         ti = (int)((sqrtf(8.f * (float)s + 1.f) - 1.f) * 0.5f);
@@ -52,75 +106,96 @@ __global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
         ti = blockIdx.x / p.Tn;
         tj = blockIdx.x - ti * p.Tn;
     }
-    const int64_t grow0 = p.row0 + (int64_t)ti * RT;   // global first row of tile
-    const int64_t gcol0 = (int64_t)tj * RT;
-    if (p.symmetric && gcol0 > grow0 + RT - 1) return;  // tile above the diagonal
+    // symmetric build: skip tiles above the diagonal
+    return !(p.symmetric && (int64_t)tj * RT > p.row0 + (int64_t)ti * RT + RT - 1);
+}
 
+__device__ __forceinline__ void rbf_finish(const RbfDev& p, int64_t gr, int64_t gc, double s0, double s1,
+                                           double* dst) {
+    double v0 = p.sig2 * exp(p.coef * s0);
+    double v1 = p.sig2 * exp(p.coef * s1);
+    if (p.symmetric) {
+        if (gr == gc) v0 = v0 + p.diag_add;
+        if (gr == gc + 1) v1 = v1 + p.diag_add;
+        // identity padding beyond the real matrix
+        if (gr >= p.nA || gc >= p.nB) v0 = (gr == gc) ? 1.0 : 0.0;
+        if (gr >= p.nA || gc + 1 >= p.nB) v1 = (gr == gc + 1) ? 1.0 : 0.0;
+    } else {
+        if (gr >= p.nA || gc >= p.nB) v0 = 0.0;
+        if (gr >= p.nA || gc + 1 >= p.nB) v1 = 0.0;
+    }
+    *reinterpret_cast<d2*>(dst) = d2{v0, v1};
+}
+
+// D > 0: d == D at compile time (b columns in registers); D == 0: runtime d <= LDS_MAXD
+template <int D>
+__global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int d = D ? D : p.d;
+    double* As = lds;               // [RT][d]   row-major: broadcast reads
+    double* Bs = lds + RT * d;      // [d][RT]   k-major: conflict-free column reads
+    int ti, tj;
+    if (!rbf_map_tile(p, ti, tj)) return;
+    const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+    const int64_t gcol0 = (int64_t)tj * RT;
     const int tid = threadIdx.x;
+    for (int e = tid; e < RT * d; e += 256) {
+        const int r = e / d, k = e - r * d;
+        const int64_t ga = grow0 + r, gb = gcol0 + r;
+        As[r * d + k] = (ga < p.nA) ? p.A[ga * d + k] : 0.0;
+        Bs[k * RT + r] = (gb < p.nB) ? p.B[gb * d + k] : 0.0;
+    }
+    __syncthreads();
     const int cp = tid & 63;       // column pair: cols 2cp, 2cp+1
     const int rg = tid >> 6;       // row group: rows 32*rg .. +32
-    double acc[32][2];
+    const int64_t gc = gcol0 + 2 * cp;
+    double* out0 = p.out + ((int64_t)ti * RT + 32 * rg) * p.ld + gc;
+    if constexpr (D > 0) {
+        double b0[D], b1[D];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) acc[r][0] = acc[r][1] = 0.0;
-
-    const int d = p.d;
-    for (int k0 = 0; k0 < d; k0 += DK) {
-        const int dk = DC ? DC : ((d - k0) < DK ? (d - k0) : DK);
-        if (k0) __syncthreads();
-        // stage rows of A and B for this k-chunk: [row][DK]
-        for (int e = tid; e < RT * dk; e += 256) {
-            const int r = e / dk, k = e - r * dk;
-            const int64_t ga = grow0 + r, gb = gcol0 + r;
-            As[r * DK + k] = (ga < p.nA) ? p.A[ga * d + k0 + k] : 0.0;
-            Bs[k * RT + r] = (gb < p.nB) ? p.B[gb * d + k0 + k] : 0.0;   // k-major: conflict-free column reads
+        for (int k = 0; k < D; ++k) {
+            const d2 bv = *reinterpret_cast<const d2*>(&Bs[k * RT + 2 * cp]);
+            b0[k] = bv.x;
+            b1[k] = bv.y;
         }
-        __syncthreads();
-        double b0[DK], b1[DK];
-#pragma unroll
-        for (int k = 0; k < DK; ++k) {
-            if (k < dk) {
-                const d2 bv = *reinterpret_cast<const d2*>(&Bs[k * RT + 2 * cp]);
-                b0[k] = bv.x;
-                b1[k] = bv.y;
-            }
-        }
-#pragma unroll
+#pragma unroll 2
         for (int r = 0; r < 32; ++r) {
-            const double* ar = &As[(32 * rg + r) * DK];
-            double s0 = acc[r][0], s1 = acc[r][1];
+            const double* ar = &As[(32 * rg + r) * D];
+            double av[D];
 #pragma unroll
-            for (int k = 0; k < DK; ++k) {
-                if (k < dk) {
-                    const double a = ar[k];
-                    const double e0 = a - b0[k];
-                    const double e1 = a - b1[k];
-                    s0 = s0 + e0 * e0;
-                    s1 = s1 + e1 * e1;
-                }
-            }
-            acc[r][0] = s0;
-            acc[r][1] = s1;
+            for (int k = 0; k < D; ++k) av[k] = ar[k];
+            const double s0 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b0[k]; });
+            const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
+            rbf_finish(p, grow0 + 32 * rg + r, gc, s0, s1, out0 + (int64_t)r * p.ld);
+        }
+    } else {
+        for (int r = 0; r < 32; ++r) {
+            const double* ar = &As[(32 * rg + r) * d];
+            const double* bc = &Bs[2 * cp];
+            const double s0 = sq_pw_small([&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT]; }, d);
+            const double s1 = sq_pw_small([&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT + 1]; }, d);
+            rbf_finish(p, grow0 + 32 * rg + r, gc, s0, s1, out0 + (int64_t)r * p.ld);
         }
     }
+}
 
+// any d: operands straight from global memory (L2-resident), one column pair per thread
+__global__ __launch_bounds__(256) void rbf_naive_kernel(const RbfDev p) {
+    int ti, tj;
+    if (!rbf_map_tile(p, ti, tj)) return;
+    const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+    const int64_t gcol0 = (int64_t)tj * RT;
+    const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int64_t gc = gcol0 + 2 * cp;
-#pragma unroll
+    const int d = p.d;
     for (int r = 0; r < 32; ++r) {
         const int64_t gr = grow0 + 32 * rg + r;
-        double v0 = p.sig2 * exp(p.coef * acc[r][0]);
-        double v1 = p.sig2 * exp(p.coef * acc[r][1]);
-        if (p.symmetric) {
-            if (gr == gc) v0 = v0 + p.diag_add;
-            if (gr == gc + 1) v1 = v1 + p.diag_add;
-            // identity padding beyond the real matrix
-            if (gr >= p.nA || gc >= p.nB) v0 = (gr == gc) ? 1.0 : 0.0;
-            if (gr >= p.nA || gc + 1 >= p.nB) v1 = (gr == gc + 1) ? 1.0 : 0.0;
-        } else {
-            if (gr >= p.nA || gc >= p.nB) v0 = 0.0;
-            if (gr >= p.nA || gc + 1 >= p.nB) v1 = 0.0;
+        double s0 = 0., s1 = 0.;
+        if (gr < p.nA) {
+            if (gc < p.nB) s0 = sq_pw_global(p.A + gr * d, p.B + gc * d, d);
+            if (gc + 1 < p.nB) s1 = sq_pw_global(p.A + gr * d, p.B + (gc + 1) * d, d);
         }
-        double* dst = p.out + ((int64_t)ti * RT + 32 * rg + r) * p.ld + gc;
-        *reinterpret_cast<d2*>(dst) = d2{v0, v1};
+        rbf_finish(p, gr, gc, s0, s1, p.out + ((int64_t)ti * RT + 32 * rg + r) * p.ld + gc);
     }
 }
 
@@ -135,15 +210,18 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     p.tri = (a.symmetric && a.row0 == 0 && p.Tm == p.Tn) ? 1 : 0;
     const int64_t nblk = p.tri ? (int64_t)p.Tm * (p.Tm + 1) / 2 : (int64_t)p.Tm * p.Tn;
     dim3 grid((unsigned)nblk), block(256);
-    switch (a.d) {
-        case 1: hipLaunchKernelGGL(rbf_kernel<1>, grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL(rbf_kernel<2>, grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL(rbf_kernel<3>, grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL(rbf_kernel<4>, grid, block, 0, s, p); break;
-        case 8: hipLaunchKernelGGL(rbf_kernel<8>, grid, block, 0, s, p); break;
-        case 16: hipLaunchKernelGGL(rbf_kernel<16>, grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL(rbf_kernel<0>, grid, block, 0, s, p); break;
+    const size_t lds = (size_t)2 * RT * a.d * sizeof(double);
+#define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_kernel<DD>, grid, block, lds, s, p); break
+    if (a.d > LDS_MAXD) {
+        hipLaunchKernelGGL(rbf_naive_kernel, grid, block, 0, s, p);
+    } else {
+        switch (a.d) {
+            RBF_CASE(1); RBF_CASE(2); RBF_CASE(3); RBF_CASE(4); RBF_CASE(5); RBF_CASE(6); RBF_CASE(7);
+            RBF_CASE(8); RBF_CASE(16);
+            default: hipLaunchKernelGGL(rbf_kernel<0>, grid, block, lds, s, p); break;
+        }
     }
+#undef RBF_CASE
     return hipGetLastError();
 }
 

@@ -52,6 +52,39 @@ def RBF_kernel_chunked(a, b, sigma, l, rows=256):
     return out
 
 
+_C_LIB = None
+
+
+def _c_lib():
+    """oracle/build/librbf_oracle.so (rbf_oracle.c), built by oracle/Makefile."""
+    global _C_LIB
+    if _C_LIB is None:
+        import ctypes as C
+        import os
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "build", "librbf_oracle.so")
+        lib = C.CDLL(path)
+        dp = C.POINTER(C.c_double)
+        lib.rbf_oracle.argtypes = [dp, C.c_int64, dp, C.c_int64, C.c_int64, C.c_double, C.c_double,
+                                   C.c_double, dp, C.c_int64]
+        lib.rbf_oracle.restype = None
+        _C_LIB = lib
+    return _C_LIB
+
+
+def RBF_kernel_c(a, b, sigma, l, diag_add=0.0):
+    """GP_regression.py:18-19 through rbf_oracle.c (same per-element arithmetic,
+    multi-threaded, no (N,d,M) temporary); diag_add folds the `+ s*np.eye(N)` of :138."""
+    import ctypes as C
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    out = np.empty((a.shape[0], b.shape[0]))
+    dp = C.POINTER(C.c_double)
+    coef = -.5 * (1 / (float(l) ** 2))
+    _c_lib().rbf_oracle(a.ctypes.data_as(dp), a.shape[0], b.ctypes.data_as(dp), b.shape[0], a.shape[1],
+                        coef, float(sigma) ** 2, float(diag_add), out.ctypes.data_as(dp), b.shape[0])
+    return out
+
+
 def dataset_generator(N, n):
     """GP_regression.py:53-68 -- consumes np.random's global state in the order
     uniform(N,1) then randn(N)."""
@@ -132,15 +165,19 @@ def bayesian_opt(X_train, X_test, y_train):
 # baseline at sizes where the (N,d,N) broadcast does not fit, and as the
 # checker at mid sizes (N of a few thousand) where LU would take minutes.
 # ---------------------------------------------------------------------------
-def fit_predict_feasible(X_train, X_test, y_train, sigma, l, s, rows=256):
+def fit_predict_feasible(X_train, X_test, y_train, sigma, l, s, rows=256, use_c=True):
     import scipy.linalg as sla
     N = len(X_train)
-    K = RBF_kernel_chunked(X_train, X_train, sigma, l, rows)
+    if use_c:
+        rbf = lambda a, b, sg, ll, rows=None: RBF_kernel_c(a, b, sg, ll)  # noqa: E731
+    else:
+        rbf = RBF_kernel_chunked
+    K = rbf(X_train, X_train, sigma, l, rows)
     K[np.diag_indices(N)] += s
     L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
     m = sla.solve_triangular(L, y_train, lower=True, check_finite=False)
     alpha = sla.solve_triangular(L, m, lower=True, trans='T', check_finite=False)
-    K_s = RBF_kernel_chunked(X_train, X_test, sigma, l, rows)
+    K_s = rbf(X_train, X_test, sigma, l, rows)
     mu = K_s.T @ alpha
     v = sla.solve_triangular(L, K_s, lower=True, overwrite_b=True, check_finite=False)
     var = sigma ** 2 - np.einsum('ij,ij->j', v, v)

@@ -1,0 +1,55 @@
+"""Host-side shim logic that needs no GPU: argument coercion, error mapping, constants."""
+import numpy as np
+import pytest
+
+from gaussian_process_amd import _lib
+from gaussian_process_amd import GP_regression as G
+from gaussian_process_amd import tune_hyperparms_regression as T
+
+
+def test_scalar_accepts_what_the_reference_passes():
+    # l[i] at tune_hyperparms_regression.py:369, np.random.uniform(0,5,1) at :408
+    assert _lib.scalar(np.array([0.7])) == 0.7
+    assert _lib.scalar(np.array(2.5)) == 2.5
+    assert _lib.scalar(3) == 3.0
+    with pytest.raises(ValueError):
+        _lib.scalar(np.array([1.0, 2.0]))
+
+
+def test_as_f64_makes_contiguous_float64():
+    a = np.arange(12, dtype=np.int32).reshape(3, 4)[:, ::2]
+    b = _lib.as_f64(a, 2)
+    assert b.dtype == np.float64 and b.flags.c_contiguous and b.shape == (3, 2)
+    with pytest.raises(ValueError):
+        _lib.as_f64(np.zeros(3), 2)
+
+
+def test_status_mapping_matches_reference_exceptions():
+    _lib.check(_lib.GPMI_OK)
+    with pytest.raises(np.linalg.LinAlgError) as ei:      # np.linalg.cholesky, GP_regression.py:138
+        _lib.check(_lib.GPMI_ERR_NOT_PD, bad_pivot=7)
+    assert ei.value.bad_pivot == 7
+    with pytest.raises(ValueError):
+        _lib.check(_lib.GPMI_ERR_BAD_ARG)
+    with pytest.raises(RuntimeError):
+        _lib.check(_lib.GPMI_ERR_RUNTIME)
+
+
+def test_constants_are_the_reference_literals():
+    assert G.NOISE_VAR == 0.0005 and G.SIGMA_F == 1 and G.POST_JITTER == 1e-6   # GP_regression.py:120-121,154
+    assert T.NOISE_VAR == 0.0005 and T.BO_NOISE_VAR == 0.0001                    # tune...:302, :75
+
+
+def test_only_rbf_is_in_scope():
+    for k in ("lin", "per"):
+        with pytest.raises(NotImplementedError):
+            G.prediction(np.zeros((2, 1)), np.zeros((2, 1)), np.zeros(2), k, 1.0, 1)
+
+
+def test_dataset_generator_follows_reference_rng_order(oracle):
+    np.random.seed(3)
+    f, X, y, Xs = G.dataset_generator(40, 9)
+    np.random.seed(3)
+    f2, X2, y2, Xs2 = oracle.dataset_generator(40, 9)
+    assert np.array_equal(X, X2) and np.array_equal(y, y2) and np.array_equal(Xs, Xs2)
+    assert X.shape == (40, 1) and y.shape == (40,) and Xs.shape == (9, 1)

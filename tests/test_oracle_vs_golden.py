@@ -1,0 +1,98 @@
+"""Pin the CPU oracle (oracle/gp_oracle.py, rbf_oracle.c) against the golden vectors
+produced by the reference itself (oracle/make_golden.py).  Runs without a GPU.
+
+Tolerances: the oracle issues the same NumPy/LAPACK calls as the reference, so on
+the machine that generated the goldens it is bit-identical; the slack below only
+covers a different host (SIMD width of np.exp, OpenBLAS thread count)."""
+import numpy as np
+import pytest
+
+from conftest import golden, golden_names
+
+K_RTOL = 1e-15          # exp() may differ by < 1 ulp between hosts
+MU_ATOL = 1e-9
+SD_ATOL = 1e-9
+LML_RTOL = 1e-11
+FPOST_ATOL = 1e-6       # Cholesky of a jitter-regularised, near-singular posterior covariance
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_rbf_kernel_matches_reference(oracle, name):
+    g = golden(name)
+    K = oracle.RBF_kernel(g["X"], g["X"], float(g["sigma"]), float(g["ell"]))
+    assert np.allclose(K[:16, :16], g["K_corner"], rtol=K_RTOL, atol=0)
+    assert np.allclose(K[-1], g["K_lastrow"], rtol=K_RTOL, atol=0)
+    assert np.allclose(K.sum(1), g["K_rowsum"], rtol=1e-14, atol=0)
+    assert abs(np.linalg.norm(K) - g["K_fro"]) <= 1e-14 * g["K_fro"]
+    assert np.array_equal(np.diag(K), np.full(len(K), float(g["sigma"]) ** 2))   # exact diagonal
+    assert np.array_equal(K, K.T)                                                 # exact symmetry
+    # the chunked and the C restatements carry the same arithmetic
+    assert np.allclose(oracle.RBF_kernel_chunked(g["X"], g["X"], float(g["sigma"]), float(g["ell"]), rows=37),
+                       K, rtol=K_RTOL, atol=0)
+    assert np.allclose(oracle.RBF_kernel_c(g["X"], g["X"], float(g["sigma"]), float(g["ell"])),
+                       K, rtol=4e-16, atol=0)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_cfg1_prediction_reproduces_reference(oracle, seed):
+    """BASELINE config 1: GP_regression.py on N=512, d=1 sine data (NumPy path)."""
+    g = golden("cfg1_seed%d" % seed)
+    np.random.seed(seed)
+    f, X, y, Xs = oracle.dataset_generator(512, 100)
+    assert np.array_equal(X, g["X"]) and np.array_equal(y, g["y"]) and np.array_equal(Xs, g["Xs"])
+    mu, sd, fpost = oracle.prediction(X, Xs, y, 'rbf', 1, 10)
+    assert np.allclose(mu, g["mu"], rtol=0, atol=MU_ATOL)
+    assert np.allclose(sd, g["sd"], rtol=0, atol=SD_ATOL)
+    assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
+    lml = oracle.compute_mar_likelihood(X, Xs, y, 1, 1)
+    assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
+
+
+@pytest.mark.parametrize("name", golden_names("d"))
+def test_multid_posterior_and_lml(oracle, name):
+    g = golden(name)
+    X, y, Xs, ell = g["X"], g["y"], g["Xs"], float(g["ell"])
+    np.random.seed(int(g["seed"]))
+    mu, sd, fpost = oracle.prediction(X, Xs, y, 'rbf', ell, 3)
+    assert np.allclose(mu, g["mu"], rtol=0, atol=MU_ATOL)
+    assert np.allclose(sd, g["sd"], rtol=0, atol=SD_ATOL)
+    assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
+    assert abs(oracle.compute_mar_likelihood(X, Xs, y, 1, ell) - g["lml"]) <= LML_RTOL * abs(g["lml"])
+    assert abs(oracle.compute_mar_likelihood(X, Xs, y, float(g["sigma2"]), float(g["ell2"])) - g["lml2"]) \
+        <= LML_RTOL * abs(g["lml2"])
+    p = oracle.posterior(X, Xs, y, 1, ell, 0.0005)
+    amax = np.abs(g["alpha"]).max()
+    assert np.allclose(p["alpha"], g["alpha"], rtol=0, atol=1e-9 * amax)
+    assert np.allclose(np.diagonal(p["L"]), g["diagL"], rtol=1e-12, atol=0)
+    # the memory-feasible restatement (true triangular solves) agrees with the LU-based reference path
+    fz = oracle.fit_predict_feasible(X, Xs, y, 1, ell, 0.0005)
+    assert np.allclose(fz["mu"], g["mu"], rtol=0, atol=1e-9)
+    assert np.allclose(np.sqrt(fz["var"]), g["sd"], rtol=0, atol=1e-9)
+    assert abs(fz["lml"] - g["lml"]) <= 1e-10 * abs(g["lml"])
+
+
+def test_edge_cases(oracle):
+    e = golden("edge_cases")
+    # N = 1, n = 1
+    np.random.seed(5)
+    mu, sd, fp = oracle.prediction(e["n1_X"], e["n1_Xs"], e["n1_y"], 'rbf', 1, 2)
+    assert np.allclose(mu, e["n1_mu"], atol=1e-14) and np.allclose(sd, e["n1_sd"], atol=1e-14)
+    assert np.allclose(fp, e["n1_fpost"], atol=1e-12)
+    assert abs(oracle.compute_mar_likelihood(e["n1_X"], None, e["n1_y"], 1, 1) - e["n1_lml"]) < 1e-13
+    # duplicate rows (exactly singular K rescued by + s I), ragged sizes
+    for tag, seed, nf in (("dup", 6, 1), ("rag", 7, 2)):
+        np.random.seed(seed)
+        mu, sd, fp = oracle.prediction(e[tag + "_X"], e[tag + "_Xs"], e[tag + "_y"], 'rbf', float(e[tag + "_ell"]), nf)
+        assert np.allclose(mu, e[tag + "_mu"], atol=1e-9)
+        assert np.allclose(sd, e[tag + "_sd"], atol=1e-9, equal_nan=True)
+        assert np.allclose(fp, e[tag + "_fpost"], atol=FPOST_ATOL)
+        lml = oracle.compute_mar_likelihood(e[tag + "_X"], None, e[tag + "_y"], 1, float(e[tag + "_ell"]))
+        assert abs(lml - e[tag + "_lml"]) <= 1e-10 * abs(e[tag + "_lml"])
+    # rectangular kernel with an array-valued lengthscale (l[i], tune_hyperparms_regression.py:369)
+    K = oracle.RBF_kernel(e["rbf_A"], e["rbf_B"], float(e["rbf_sigma"]), np.array([float(e["rbf_ell"])]))
+    assert K.shape == (33, 65) and np.allclose(K, e["rbf_K"], rtol=K_RTOL, atol=0)
+    # not positive definite -> LinAlgError, as np.linalg.cholesky does in the reference
+    assert int(e["npd_raised"]) == 1
+    Kn = oracle.RBF_kernel(e["npd_X"], e["npd_X"], 1, float(e["npd_ell"]))
+    with pytest.raises(np.linalg.LinAlgError):
+        np.linalg.cholesky(Kn + float(e["npd_shift"]) * np.eye(len(Kn)))

@@ -1,0 +1,335 @@
+"""Parity of the HIP path (through the C-ABI, via the ctypes shim) with the reference.
+
+Checked against (a) the golden vectors the reference itself produced
+(tests/golden/, oracle/make_golden.py) and (b) the CPU oracle on seeded inputs.
+All tolerances are fp64 and stated here; BASELINE.json's bar is predictive mean
+within 1e-8 of NumPy -- the small cases are held to much tighter bounds.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, golden_names
+
+pytestmark = pytest.mark.gpu
+
+K_RTOL = 7e-16        # 3 ulp: identical exp argument, exp itself < 1 ulp on both sides
+MU_ATOL = 1e-9        # north_star: 1e-8
+SD_ATOL = 1e-9
+VAR_ATOL = 1e-10
+LML_RTOL = 1e-10
+ALPHA_RTOL = 1e-8     # relative to max|alpha| (alpha carries cond(K+sI) * eps)
+M_RTOL = 1e-9
+DIAG_RTOL = 1e-11
+FPOST_ATOL = 1e-6     # Cholesky of the jitter-regularised posterior covariance
+
+
+def relmax(a, b):
+    return np.max(np.abs(a - b)) / np.max(np.abs(b))
+
+
+# ----------------------------------------------------------------------------- a1
+@pytest.mark.parametrize("name", golden_names())
+def test_rbf_kernel_vs_reference_golden(ctx, name):
+    g = golden(name)
+    K = ctx.rbf(g["X"], g["X"], float(g["sigma"]), float(g["ell"]))
+    assert K.shape == (len(g["X"]),) * 2 and K.dtype == np.float64
+    assert np.allclose(K[:16, :16], g["K_corner"], rtol=K_RTOL, atol=0)
+    assert np.allclose(K[-1], g["K_lastrow"], rtol=K_RTOL, atol=0)
+    assert np.allclose(K.sum(1), g["K_rowsum"], rtol=1e-14, atol=0)
+    assert abs(np.linalg.norm(K) - g["K_fro"]) <= 1e-14 * g["K_fro"]
+    # direct-difference form: exact diagonal and exact symmetry, as in the reference
+    assert np.array_equal(np.diag(K), np.full(len(K), float(g["sigma"]) ** 2))
+    assert np.array_equal(K, K.T)
+    if "Ks_corner" in g:
+        Ks = ctx.rbf(g["X"], g["Xs"], float(g["sigma"]), float(g["ell"]))
+        assert np.allclose(Ks[:16, :16], g["Ks_corner"], rtol=K_RTOL, atol=0)
+        assert np.allclose(Ks.sum(0), g["Ks_colsum"], rtol=1e-14, atol=0)
+
+
+@pytest.mark.parametrize("N,M,d", [(1, 1, 1), (1, 9, 3), (130, 77, 1), (77, 130, 2), (129, 129, 5), (64, 300, 7),
+                                   (200, 200, 8), (257, 131, 9), (100, 100, 16), (90, 140, 17), (70, 70, 32),
+                                   (60, 50, 33), (40, 45, 130), (33, 29, 300)])
+def test_rbf_kernel_shapes_and_summation_order(ctx, oracle, N, M, d):
+    rng = np.random.default_rng(1000 * N + d)
+    a = rng.uniform(-2, 2, (N, d))
+    b = rng.uniform(-2, 2, (M, d))
+    ell = 1.5 * np.sqrt(d)
+    K = ctx.rbf(a, b, 1.7, ell)
+    ref = oracle.RBF_kernel(a, b, 1.7, ell)          # the reference's broadcast formula
+    assert K.shape == (N, M)
+    assert np.allclose(K, ref, rtol=K_RTOL, atol=0)
+
+
+def test_rbf_kernel_accepts_array_lengthscale_and_rejects_bad_input(ctx):
+    e = golden("edge_cases")
+    K = ctx.rbf(e["rbf_A"], e["rbf_B"], float(e["rbf_sigma"]), np.array([float(e["rbf_ell"])]))
+    assert np.allclose(K, e["rbf_K"], rtol=K_RTOL, atol=0)
+    with pytest.raises(ValueError):
+        ctx.rbf(np.zeros((3, 2)), np.zeros((3, 4)), 1.0, 1.0)       # d mismatch
+    with pytest.raises(ValueError):
+        ctx.rbf(np.zeros((3, 2)), np.zeros((3, 2)), 1.0, 0.0)       # ell == 0
+    with pytest.raises(ValueError):
+        ctx.rbf(np.zeros((3, 2)), np.zeros((3, 2)), 1.0, np.array([1.0, 2.0]))
+
+
+# ------------------------------------------------------------------- a2..a8, a10, f1
+@pytest.mark.parametrize("name", golden_names())
+def test_fit_predict_vs_reference_golden(ctx, name):
+    g = golden(name)
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    lml = ctx.fit(X, y, float(g["sigma"]), float(g["ell"]), float(g["s"]))
+    assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
+    assert relmax(ctx.diag(), g["diagL"]) <= DIAG_RTOL
+    assert relmax(ctx.m(), g["m"]) <= M_RTOL
+    assert relmax(ctx.alpha(), g["alpha"]) <= ALPHA_RTOL
+    mu, sd = ctx.predict(Xs, want_sd=True)
+    assert np.allclose(mu, g["mu"], rtol=0, atol=MU_ATOL)
+    assert np.allclose(sd, g["sd"], rtol=0, atol=SD_ATOL)
+    mu2, var = ctx.predict_resident(want_sd=False)
+    assert np.array_equal(mu, mu2)                       # deterministic
+    assert np.allclose(var, g["sd"] ** 2, rtol=0, atol=VAR_ATOL)
+    L_ = ctx.post_chol(1e-6)
+    assert np.array_equal(L_, np.tril(L_))
+    fpost = mu.reshape(-1, 1) + L_ @ g["normals"]
+    assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_dropin_prediction_cfg1(seed):
+    """BASELINE config 1 through the drop-in module: same RNG stream as the reference."""
+    from gaussian_process_amd import GP_regression as G
+    g = golden("cfg1_seed%d" % seed)
+    np.random.seed(seed)
+    f, X, y, Xs = G.dataset_generator(512, 100)
+    assert np.array_equal(X, g["X"]) and np.array_equal(y, g["y"])
+    mu, sd, fpost = G.prediction(X, Xs, y, 'rbf', 1, 10)
+    assert mu.shape == (100,) and sd.shape == (100,) and fpost.shape == (100, 10)
+    assert np.allclose(mu, g["mu"], rtol=0, atol=MU_ATOL)
+    assert np.allclose(sd, g["sd"], rtol=0, atol=SD_ATOL)
+    assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
+    assert np.max(np.abs(mu - f(Xs))) < 0.05              # it still regresses the sine
+
+
+@pytest.mark.parametrize("name", golden_names("d"))
+def test_dropin_compute_mar_likelihood(name):
+    from gaussian_process_amd import GP_regression as G
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    g = golden(name)
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    lml = T.compute_mar_likelihood(X, Xs, y, 1, np.array([float(g["ell"])]))   # l[i]-style argument
+    assert isinstance(lml, np.float64)
+    assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
+    lml2 = T.compute_mar_likelihood(X, Xs, y, float(g["sigma2"]), float(g["ell2"]))
+    assert abs(lml2 - g["lml2"]) <= LML_RTOL * abs(g["lml2"])
+    K = G.RBF_kernel(X, Xs, 1, float(g["ell"]))
+    assert np.allclose(K[:16, :16], g["Ks_corner"], rtol=K_RTOL, atol=0)
+
+
+def test_lml_batch_matches_per_call_oracle(ctx, oracle):
+    g = golden("d8_box1_N256")
+    X, y = g["X"], g["y"]
+    triples = np.array([[l, sf, s2] for l in (1.0, 2.0, 3.5) for sf in (0.5, 1.5) for s2 in (1e-4, 5e-4)])
+    ctx.set_train(X, y)
+    lml, status = ctx.lml_batch(triples)
+    assert np.all(status == 0)
+    for t, (l, sf, s2) in enumerate(triples):
+        ref = oracle.compute_mar_likelihood(X, None, y, sf, l, s=s2)
+        assert abs(lml[t] - ref) <= LML_RTOL * abs(ref), (t, lml[t], ref)
+    # entries with the hard-coded s = 5e-4 equal the drop-in single call
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    assert T.compute_mar_likelihood(X, None, y, 1.5, 2.0, ctx=ctx) == lml[7]
+    # a non-PD triple in the middle of a batch: NaN + status, the rest unaffected
+    bad = np.array([[2.0, 1.0, 5e-4], [2.0, 1.0, -0.9], [2.0, 1.0, 5e-4]])
+    lml_b, st_b = ctx.lml_batch(bad)
+    assert st_b.tolist() == [0, 1, 0] and np.isnan(lml_b[1]) and lml_b[0] == lml_b[2]
+    out = T.compute_mar_likelihood_batch(X, y, triples[:3], ctx=ctx)
+    assert np.array_equal(out, lml[:3])
+
+
+def test_bayesian_opt_surrogate(ctx, oracle):
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    rng = np.random.default_rng(4)
+    Xh = rng.uniform(0.02, 5, (5, 1))          # <= 5 hyper-parameter points (tune...:418-432)
+    yh = -(Xh[:, 0] - 2.0) ** 2
+    Xt = np.linspace(0.02, 5, 100).reshape(-1, 1)
+    np.random.seed(9)
+    mu, sd, fp = T.bayesian_opt(Xh, Xt, yh, ctx=ctx)
+    np.random.seed(9)
+    mu_r, sd_r, fp_r = oracle.bayesian_opt(Xh, Xt, yh)
+    assert fp.shape == (100, 1)
+    assert np.allclose(mu, mu_r, atol=1e-10) and np.allclose(sd, sd_r, atol=1e-9, equal_nan=True)
+    assert np.allclose(fp, fp_r, atol=FPOST_ATOL)
+
+
+def test_f_prior(ctx, oracle):
+    from gaussian_process_amd import GP_regression as G
+    Xt = np.linspace(-5, 5, 150).reshape(-1, 1)
+    np.random.seed(2)
+    fp = G.f_prior(Xt, np.zeros((150, 1)), 'rbf', 1.0, 4, ctx=ctx)
+    np.random.seed(2)
+    B = np.linalg.cholesky(oracle.RBF_kernel(Xt, Xt, 1, 1.0) + 0.0005 * np.eye(150))   # GP_regression.py:90
+    ref = np.zeros((150, 1)) + B @ np.random.normal(size=(150, 4))
+    assert np.allclose(fp, ref, atol=1e-9)
+
+
+# ----------------------------------------------------------------------- edge cases
+def test_edge_cases_vs_reference_golden(ctx):
+    e = golden("edge_cases")
+    # N = 1, n = 1
+    lml = ctx.fit(e["n1_X"], e["n1_y"], 1, 1, 0.0005)
+    mu, sd = ctx.predict(e["n1_Xs"])
+    assert abs(lml - e["n1_lml"]) < 1e-13
+    assert np.allclose(mu, e["n1_mu"], atol=1e-14) and np.allclose(sd, e["n1_sd"], atol=1e-13)
+    np.random.seed(5)
+    L_ = ctx.post_chol(1e-6)
+    assert np.allclose(mu.reshape(-1, 1) + L_ @ np.random.normal(size=(1, 2)), e["n1_fpost"], atol=1e-12)
+    # duplicate rows (exactly singular K, rescued by + s I) and ragged sizes (n > N, no tile multiple)
+    for tag in ("dup", "rag"):
+        X, y, Xs, ell = e[tag + "_X"], e[tag + "_y"], e[tag + "_Xs"], float(e[tag + "_ell"])
+        lml = ctx.fit(X, y, 1, ell, 0.0005)
+        mu, sd = ctx.predict(Xs)
+        assert abs(lml - e[tag + "_lml"]) <= LML_RTOL * abs(e[tag + "_lml"])
+        assert np.allclose(mu, e[tag + "_mu"], atol=MU_ATOL)
+        assert np.allclose(sd, e[tag + "_sd"], atol=SD_ATOL, equal_nan=True)
+
+
+def test_not_positive_definite_raises_linalgerror(ctx):
+    e = golden("edge_cases")
+    X = e["npd_X"]
+    y = np.ones(len(X))
+    with pytest.raises(np.linalg.LinAlgError) as ei:      # reference: np.linalg.cholesky, GP_regression.py:138
+        ctx.fit(X, y, 1, float(e["npd_ell"]), float(e["npd_shift"]))
+    assert 1 <= ei.value.bad_pivot <= len(X)
+    with pytest.raises(ValueError):                       # no factor resident after the failure
+        ctx.alpha()
+    # the context stays usable
+    lml = ctx.fit(X, y, 1, float(e["npd_ell"]), 0.0005)
+    assert np.isfinite(lml)
+    # the first failing pivot is the one LAPACK reports: leading minor of order k not PD
+    K = np.exp(-.5 * (1 / (float(e["npd_ell"]) ** 2)) * ((X[:, None, :] - X[None, :, :]) ** 2).sum(2)) \
+        + float(e["npd_shift"]) * np.eye(len(X))
+    k = next(i for i in range(1, len(X) + 1) if np.linalg.eigvalsh(K[:i, :i]).min() <= 0)
+    with pytest.raises(np.linalg.LinAlgError) as ei:
+        ctx.fit(X, y, 1, float(e["npd_ell"]), float(e["npd_shift"]))
+    assert ei.value.bad_pivot == k
+
+
+def test_argument_errors(ctx):
+    with pytest.raises(ValueError):
+        ctx.fit(np.zeros((4, 2)), np.zeros(5), 1, 1, 5e-4)      # y length mismatch
+    ctx.fit(np.random.default_rng(0).normal(size=(10, 2)), np.zeros(10), 1, 1, 5e-4)
+    with pytest.raises(ValueError):
+        ctx.predict(np.zeros((3, 5)))                           # d mismatch
+    with pytest.raises(ValueError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        ctx.set_option("nb", 100)
+
+
+# ------------------------------------------------------------------ algebraic checks
+def test_factor_reconstructs_matrix(ctx, oracle):
+    rng = np.random.default_rng(7)
+    X = rng.uniform(-1, 1, (300, 4))
+    y = rng.normal(size=300)
+    ctx.fit(X, y, 1.2, 0.8, 1e-3)
+    L = ctx.factor()
+    assert np.array_equal(L, np.tril(L))
+    K = oracle.RBF_kernel(X, X, 1.2, 0.8) + 1e-3 * np.eye(300)
+    assert np.max(np.abs(L @ L.T - K)) < 1e-13
+    assert np.allclose(L, np.linalg.cholesky(K), atol=1e-11)
+    assert np.allclose(ctx.factor(100, 180, 20, 150), L[100:180, 20:150])
+
+
+@pytest.mark.parametrize("nb", [128, 256, 384, 512])
+def test_blocking_does_not_change_results(ctx, nb):
+    g = golden("d8_box1_N1024")
+    try:
+        ctx.set_option("nb", nb)
+        lml = ctx.fit(g["X"], g["y"], 1.0, 2.0, 5e-4)
+        mu, sd = ctx.predict(g["Xs"])
+    finally:
+        ctx.set_option("nb", 512)
+    assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
+    assert np.allclose(mu, g["mu"], atol=MU_ATOL) and np.allclose(sd, g["sd"], atol=SD_ATOL)
+
+
+def test_bitwise_reproducible(ctx):
+    g = golden("d8_box5_N1024")
+    res = []
+    for _ in range(2):
+        lml = ctx.fit(g["X"], g["y"], 1.0, 4.0, 5e-4)
+        mu, sd = ctx.predict(g["Xs"])
+        res.append((lml, mu.copy(), sd.copy(), ctx.alpha()))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+
+
+# ------------------------------------------------------------------ larger sizes
+def test_mid_size_vs_oracle_N4096(ctx, oracle):
+    X, y, Xs = oracle.synthetic_problem(4096, 8, 512)
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 2.0, 5e-4)
+    lml = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    mu, var = ctx.predict(Xs, want_sd=False)
+    assert np.allclose(mu, ref["mu"], rtol=0, atol=MU_ATOL)
+    assert np.allclose(var, ref["var"], rtol=0, atol=VAR_ATOL)
+    assert abs(lml - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
+    assert relmax(ctx.alpha(), ref["alpha"]) <= ALPHA_RTOL
+    assert relmax(ctx.diag(), ref["diagL"]) <= DIAG_RTOL
+
+
+def test_cfg2_N16384_d8_vs_oracle(ctx, oracle):
+    """BASELINE config 2: N=16384, d=8, predictive mean/var vs NumPy, tol 1e-8."""
+    X, y, Xs = oracle.synthetic_problem(16384, 8, 1024)
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 2.0, 5e-4)
+    lml = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    mu, var = ctx.predict(Xs, want_sd=False)
+    assert np.max(np.abs(mu - ref["mu"])) <= 1e-8
+    assert np.max(np.abs(var - ref["var"])) <= 1e-8
+    assert abs(lml - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
+
+
+def _check_solution_properties(ctx, X, y, Xs, sigma, ell, s, rows=24):
+    """Size-independent properties: alpha solves (K + sI) alpha = y on sampled rows,
+    variances lie in [0, sigma^2], the mean interpolates the targets within the noise."""
+    lml = ctx.fit(X, y, sigma, ell, s)
+    assert np.isfinite(lml)
+    alpha = ctx.alpha()
+    m = ctx.m()
+    dg = ctx.diag()
+    assert np.all(dg > 0) and np.all(np.isfinite(alpha))
+    rng = np.random.default_rng(5)
+    idx = rng.choice(len(X), rows, replace=False)
+    coef = -.5 * (1 / (ell ** 2))
+    worst = 0.0
+    for i in idx:
+        ki = sigma ** 2 * np.exp(coef * ((X - X[i]) ** 2).sum(1))
+        ki[i] += s
+        worst = max(worst, abs(ki @ alpha - y[i]))
+    assert worst <= 1e-7 * max(1.0, np.abs(alpha).max() * 1e-3), worst
+    # y^T alpha == m^T m (the identity the LML uses)
+    assert abs(y @ alpha - m @ m) <= 1e-8 * abs(m @ m)
+    mu, var = ctx.predict(Xs, want_sd=False)
+    assert np.all(var > -1e-9) and np.all(var <= sigma ** 2 + 1e-12)
+    # prediction at (a subset of) the training inputs reproduces y within a few noise sd
+    mu_tr, var_tr = ctx.predict(X[idx], want_sd=False)
+    assert np.max(np.abs(mu_tr - y[idx])) < 6 * np.sqrt(s)
+    # mean through K_s^T alpha (the reference's formula, GP_regression.py:143) on sampled test points
+    for j in range(0, len(Xs), max(1, len(Xs) // 8)):
+        kj = sigma ** 2 * np.exp(coef * ((X - Xs[j]) ** 2).sum(1))
+        assert abs(kj @ alpha - mu[j]) <= 1e-7
+    return lml
+
+
+def test_cfg3_N65536_d8_properties(ctx, oracle):
+    """BASELINE config 3 (the headline size): no CPU oracle can run it,
+    so it is checked through size-independent properties."""
+    X, y, Xs = oracle.synthetic_problem(65536, 8, 4096)
+    _check_solution_properties(ctx, X, y, Xs, 1.0, 2.0, 5e-4)
+    t = ctx.timers()
+    assert t["solve_v"] > 0 and t["ks"] > 0
+
+
+def test_d16_N8192_properties(ctx, oracle):
+    X, y, Xs = oracle.synthetic_problem(8192, 16, 300)
+    _check_solution_properties(ctx, X, y, Xs, 1.0, 2.8, 5e-4)
