@@ -291,7 +291,7 @@ def test_cfg2_N16384_d8_vs_oracle(ctx, oracle):
 
 def _check_solution_properties(ctx, X, y, Xs, sigma, ell, s, rows=24):
     """Size-independent properties: alpha solves (K + sI) alpha = y on sampled rows,
-    variances lie in [0, sigma^2], the mean interpolates the targets within the noise."""
+    variances lie in [0, sigma^2], the mean at training inputs equals y - s*alpha."""
     lml = ctx.fit(X, y, sigma, ell, s)
     assert np.isfinite(lml)
     alpha = ctx.alpha()
@@ -311,9 +311,10 @@ def _check_solution_properties(ctx, X, y, Xs, sigma, ell, s, rows=24):
     assert abs(y @ alpha - m @ m) <= 1e-8 * abs(m @ m)
     mu, var = ctx.predict(Xs, want_sd=False)
     assert np.all(var > -1e-9) and np.all(var <= sigma ** 2 + 1e-12)
-    # prediction at (a subset of) the training inputs reproduces y within a few noise sd
+    # prediction at training inputs: K_i alpha = y_i - s*alpha_i exactly (row i of (K+sI) alpha = y)
     mu_tr, var_tr = ctx.predict(X[idx], want_sd=False)
-    assert np.max(np.abs(mu_tr - y[idx])) < 6 * np.sqrt(s)
+    assert np.max(np.abs(mu_tr - (y[idx] - s * alpha[idx]))) <= 1e-7
+    assert np.all(var_tr < 2 * s)                      # and the posterior is confident there
     # mean through K_s^T alpha (the reference's formula, GP_regression.py:143) on sampled test points
     for j in range(0, len(Xs), max(1, len(Xs) // 8)):
         kj = sigma ** 2 * np.exp(coef * ((X - Xs[j]) ** 2).sum(1))
