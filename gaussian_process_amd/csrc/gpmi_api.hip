@@ -69,11 +69,13 @@ struct TimedSpan { hipEvent_t a, b; int slot; };
 
 struct gpmi_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // main stream: K build, trailing updates, reductions
+    hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
     // options
     int64_t nb = 512;       // outer block width of the Cholesky (multiple of 128)
     int64_t ld_pad = 544;   // doubles added to every leading dimension
     int timing = 1;
+    int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
     // training set / factor
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
     bool have_train = false, have_factor = false;
@@ -97,16 +99,23 @@ struct gpmi_ctx {
         }
         return ev_pool[ev_used++];
     }
-    size_t span_begin(int slot) {
+    size_t span_begin(int slot, hipStream_t st = nullptr) {
         if (!timing) return 0;
         TimedSpan s{new_event(), new_event(), slot};
-        (void)hipEventRecord(s.a, stream);
+        (void)hipEventRecord(s.a, st ? st : stream);
         spans.push_back(s);
         return spans.size() - 1;
     }
-    void span_end(size_t idx) {
+    void span_end(size_t idx, hipStream_t st = nullptr) {
         if (!timing) return;
-        (void)hipEventRecord(spans[idx].b, stream);
+        (void)hipEventRecord(spans[idx].b, st ? st : stream);
+    }
+    // make stream `waiter` wait for everything queued so far on `signaller`
+    hipError_t order(hipStream_t signaller, hipStream_t waiter) {
+        hipEvent_t e = new_event();
+        hipError_t r = hipEventRecord(e, signaller);
+        if (r != hipSuccess) return r;
+        return hipStreamWaitEvent(waiter, e, 0);
     }
     void timers_reset(std::initializer_list<int> slots) {
         for (int s : slots) stage_ms[s] = 0.;
@@ -183,34 +192,59 @@ hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, in
 
 // In-place blocked right-looking Cholesky of the leading ncols x ncols block of
 // A; rows ncols..nrows-1 are carried along (they end up multiplied by L^-T).
+//
+// With lookahead the trailing update of step k is split in two launches on the
+// main stream: (a) the next block column only, (b) the rest.  The panel stream
+// (high priority) factors panel k+1 as soon as (a) is done, i.e. concurrently
+// with (b), whose tiles it neither reads nor writes.  Dependencies:
+//   panel k  ->  (a)_k, (b)_k          (main waits on the panel event)
+//   (a)_k    ->  panel k+1             (panel stream waits on the column event)
+//   (b)_k    ->  (a)_{k+1}, (b)_{k+1}  (same stream)
 hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows,
                             int64_t* info, bool account) {
     hipError_t e;
-    hipStream_t s = c->stream;
+    hipStream_t sm = c->stream;
+    const bool la = c->lookahead && c->pstream && ncols > c->nb;
+    hipStream_t sp_ = la ? c->pstream : sm;
+    const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
+    const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
+    if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;   // panel 0 after the K build
+    auto trail = [&](int64_t r0, int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
+        // C = A[r0.., c0..c0+ncol_upd) -= A[r0.., k..k+nb) * A[c0.., k..k+nb)^T, lower part
+        GemmArgs g;
+        g.C = A + r0 * ld + c0;
+        g.A = A + r0 * ld + k;
+        g.B = A + c0 * ld + k;
+        g.ldc = g.lda = g.ldb = ld;
+        g.M = nrows - r0; g.N = ncol_upd; g.K = nb;
+        g.mode = 0; g.lower = 1; g.diag_off = r0 - c0;
+        size_t sp = c->span_begin(slot_t, sm);
+        hipError_t er = launch_gemm_nt(sm, g);
+        c->span_end(sp, sm);
+        if (account) {
+            c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
+            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_flops(g);
+        }
+        return er;
+    };
     for (int64_t k = 0; k < ncols; k += c->nb) {
         const int64_t nb = std::min<int64_t>(c->nb, ncols - k);
-        size_t sp = c->span_begin(account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1);
-        e = panel_factor(s, A + k * ld + k, ld, nb, nrows - k, k, info);
-        c->span_end(sp);
+        size_t sp = c->span_begin(slot_p, sp_);
+        e = panel_factor(sp_, A + k * ld + k, ld, nb, nrows - k, k, info);
+        c->span_end(sp, sp_);
         if (e != hipSuccess) return e;
+        if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
         const int64_t r0 = k + nb;
-        if (r0 < nrows && r0 < ncols) {
-            GemmArgs g;
-            g.C = A + r0 * ld + r0;
-            g.A = A + r0 * ld + k;
-            g.B = g.A;
-            g.ldc = g.lda = g.ldb = ld;
-            g.M = nrows - r0; g.N = ncols - r0; g.K = nb;
-            g.mode = 0; g.lower = 1; g.diag_off = 0;
-            sp = c->span_begin(account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1);
-            e = launch_gemm_nt(s, g);
-            c->span_end(sp);
-            if (e != hipSuccess) return e;
-            if (account) {
-                c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
-                c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_flops(g);
-            }
+        if (r0 >= ncols) continue;
+        if (!la) {
+            if ((e = trail(r0, r0, k, nb, ncols - r0)) != hipSuccess) return e;
+            continue;
         }
+        const int64_t nbn = std::min<int64_t>(c->nb, ncols - r0);
+        if ((e = trail(r0, r0, k, nb, nbn)) != hipSuccess) return e;           // (a) next block column
+        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
+        if (r0 + nbn < ncols &&
+            (e = trail(r0 + nbn, r0 + nbn, k, nb, ncols - r0 - nbn)) != hipSuccess) return e;  // (b) rest
     }
     return hipSuccess;
 }
@@ -283,24 +317,39 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     return GPMI_OK;
 }
 
-// v^T = K_s^T L^-T: right-looking sweep over the block columns of L
+// v^T = K_s^T L^-T: right-looking sweep over the block columns of L, with the
+// same lookahead split as the Cholesky (the triangular solve of block column
+// k+1 overlaps the update of the columns beyond it).
 hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
     hipError_t e;
-    hipStream_t s = c->stream;
+    hipStream_t sm = c->stream;
     const double* A = c->A.as<double>();
     const int64_t ld = c->ldA, Np = c->Np;
+    const bool la = c->lookahead && c->pstream && Np > c->nb;
+    hipStream_t sp_ = la ? c->pstream : sm;
+    if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
+    auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
+        GemmArgs g;   // V[:, c0..c0+ncol_upd) -= V[:, k..k+nb) * L[c0.., k..k+nb)^T
+        g.C = V + c0; g.A = V + k; g.B = A + c0 * ld + k;
+        g.ldc = g.lda = ldv; g.ldb = ld;
+        g.M = m; g.N = ncol_upd; g.K = nb;
+        g.mode = 0; g.lower = 0; g.diag_off = 0;
+        return launch_gemm_nt(sm, g);
+    };
     for (int64_t k = 0; k < Np; k += c->nb) {
         const int64_t nb = std::min<int64_t>(c->nb, Np - k);
-        if ((e = trsm_block(s, A + k * ld + k, ld, V + k, ldv, m, nb)) != hipSuccess) return e;
+        if ((e = trsm_block(sp_, A + k * ld + k, ld, V + k, ldv, m, nb)) != hipSuccess) return e;
+        if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
         const int64_t r0 = k + nb;
-        if (r0 < Np) {
-            GemmArgs g;
-            g.C = V + r0; g.A = V + k; g.B = A + r0 * ld + k;
-            g.ldc = g.lda = ldv; g.ldb = ld;
-            g.M = m; g.N = Np - r0; g.K = nb;
-            g.mode = 0; g.lower = 0; g.diag_off = 0;
-            if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
+        if (r0 >= Np) continue;
+        if (!la) {
+            if ((e = update(r0, k, nb, Np - r0)) != hipSuccess) return e;
+            continue;
         }
+        const int64_t nbn = std::min<int64_t>(c->nb, Np - r0);
+        if ((e = update(r0, k, nb, nbn)) != hipSuccess) return e;
+        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
+        if (r0 + nbn < Np && (e = update(r0 + nbn, k, nb, Np - r0 - nbn)) != hipSuccess) return e;
     }
     return hipSuccess;
 }
@@ -330,11 +379,17 @@ int gpmi_ctx_create(int device, gpmi_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     gpmi_ctx* c = new gpmi_ctx();
     c->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo);
     if (e != hipSuccess) { delete c; return fail_runtime(e, "hipStreamCreate"); }
+    e = hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, prio_hi);
+    if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail_runtime(e, "hipStreamCreate"); }
     const char* env;
     if ((env = getenv("GPMI_NB"))) c->nb = std::max<int64_t>(128, atoll(env) / 128 * 128);
     if ((env = getenv("GPMI_LD_PAD"))) c->ld_pad = std::max<int64_t>(0, atoll(env) / 2 * 2);
+    if ((env = getenv("GPMI_LOOKAHEAD"))) c->lookahead = atoi(env) ? 1 : 0;
+    if ((env = getenv("GPMI_GEMM_STAGGER"))) g_gemm_stagger = atoi(env) ? 1 : 0;
     *out = c;
     return GPMI_OK;
 }
@@ -347,6 +402,7 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
         b->release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->pstream);
     delete c;
     return GPMI_OK;
 }
@@ -362,6 +418,10 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->have_factor = c->have_v = false;
     } else if (!strcmp(name, "timing")) {
         c->timing = value ? 1 : 0;
+    } else if (!strcmp(name, "lookahead")) {
+        c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_stagger")) {
+        g_gemm_stagger = value ? 1 : 0;
     } else {
         return fail_arg("gpmi_set_option: unknown option");
     }

@@ -24,6 +24,7 @@ struct GemmArgs {
     int64_t diag_off;
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
+extern int g_gemm_stagger;   // tuning switch (GPMI_GEMM_STAGGER / option "gemm_stagger")
 // number of tiles the launch actually computes (for flop accounting)
 double gemm_nt_flops(const GemmArgs& a);
 

@@ -1,9 +1,8 @@
 // Panel kernels of the blocked Cholesky: the 64 x 64 diagonal-block
 // factorisation and the triangular solve of the rows below it.
 //
-// Both keep one matrix ROW per lane in registers (64 f64 = 128 VGPRs) and run
-// the textbook recurrences fully unrolled, so that every array index is a
-// compile-time constant (no scratch).  They replace the inner loops of LAPACK
+// Both run the textbook recurrences fully unrolled with the matrix in registers
+// (every array index a compile-time constant, no scratch).  They replace the inner loops of LAPACK
 // dpotrf / the LU-based np.linalg.solve the reference calls at
 // GP_regression.py:138-139; their share of the flops is O(N^2 * 64), the
 // O(N^3) part runs in gemm_nt.hip.
@@ -21,83 +20,148 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // ---------------------------------------------------------------------------
-// potf2_64: right-looking unblocked Cholesky of a 64 x 64 block, one wavefront.
-// Lane r owns row r.  Step j: pivot = A[j][j] broadcast with v_readlane,
-// column j scaled, then every lane updates its row with the (broadcast)
-// entries of column j.  A non-positive (or NaN) pivot records
-// col_offset + j in *info (atomic min) and poisons the block with NaN.
+// potf2_64: right-looking unblocked Cholesky of a 64 x 64 block by one workgroup
+// of 256 threads, ONE barrier per column.
+// Thread (ty, tx) = (tid >> 4, tid & 15) keeps the 4 x 4 elements
+// A[ty + 16 i][tx + 16 jj] in registers.  Step j: every thread reads the current
+// (unscaled) column j from LDS -- c_r = A[r][j] -- and the pivot p = c_j, and
+// applies   A[r][c] -= c_r * c_c / p   (= l_r * l_c with l = c / sqrt(p));
+// the owners of column j+1 then publish their updated column for the next step.
+// 1/p is a v_rcp_f64 refined by two Newton steps, evaluated redundantly by all
+// threads (no second barrier for a broadcast).  The owners of column j scale
+// their copy by 1/sqrt(p) (v_rsq_f64 + coupled Newton steps, off the critical
+// path).  A non-positive (or NaN) pivot records col_offset + j in *info
+// (atomic min) and poisons the block with NaN.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void sqrt_and_rsqrt(double p, double& s, double& rinv) {
+    const double y = __builtin_amdgcn_rsq(p);   // ~2^-26 relative
+    double g = p * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, p);             // residual p - g^2
+    s = fma(d, h, g);
+    rinv = h + h;
+}
+
+__device__ __forceinline__ double fast_rcp(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-p, y, 1.0);
+    return fma(y, e, y);
+}
+
 template <int J>
 struct Potf2Step {
-    static __device__ __forceinline__ void run(double (&a)[64], int lane, int64_t col_offset,
-                                               int64_t* info) {
-        const double piv = readlane_f64(a[J], J);
-        if (!(piv > 0.0)) {
-            if (lane == 0) atomicMin((unsigned long long*)info, (unsigned long long)(col_offset + J));
-        }
-        const double s = sqrt(piv);     // NaN for a negative pivot: poisons what follows
-        const double l = a[J] / s;      // lanes < J hold upper-triangle garbage, never stored
-        a[J] = (lane == J) ? s : l;
+    static __device__ __forceinline__ void run(double (&a)[4][4], int tx, int ty, int64_t col_offset,
+                                               int64_t* info, double* colbuf) {
+        __syncthreads();                         // column J (unscaled) is in colbuf[J & 1]
+        const double* cb = colbuf + (J & 1) * 64;
+        const double piv = cb[J];
+        if (!(piv > 0.0) && threadIdx.x == 0)
+            atomicMin((unsigned long long*)info, (unsigned long long)(col_offset + J));
+        double cr[4], cc[4];
 #pragma unroll
-        for (int c = J + 1; c < 64; ++c) {
-            const double lc = readlane_f64(l, c);
-            a[c] = fma(-l, lc, a[c]);
+        for (int i = 0; i < 4; ++i) { cr[i] = cb[ty + 16 * i]; cc[i] = cb[tx + 16 * i]; }
+        const double ip = (piv > 0.0) ? fast_rcp(piv) : __builtin_nan("");
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (16 * jj + 15 > J) {              // tile column still has columns > J
+                const double w = cc[jj] * ip;
+                const bool live = (tx + 16 * jj) > J;
+#pragma unroll
+                for (int i = jj; i < 4; ++i)     // lower tiles only (i >= jj)
+                    if (live) a[i][jj] = fma(-cr[i], w, a[i][jj]);
+            }
         }
-        Potf2Step<J + 1>::run(a, lane, col_offset, info);
+        constexpr int JT = J >> 4;               // tile column of column J
+        // owners of column J+1 publish it (rows above J+1 are never read)
+        if constexpr (J < 63) {
+            constexpr int NT = (J + 1) >> 4;
+            if (tx == ((J + 1) & 15)) {
+                double* nb = colbuf + ((J + 1) & 1) * 64;
+#pragma unroll
+                for (int i = NT; i < 4; ++i) nb[ty + 16 * i] = a[i][NT];
+            }
+        }
+        // owners of column J turn their unscaled copy into L (off the critical path)
+        if (tx == (J & 15)) {
+            double s, rinv;
+            sqrt_and_rsqrt(piv, s, rinv);
+#pragma unroll
+            for (int i = JT; i < 4; ++i) {
+                const int r = ty + 16 * i;
+                a[i][JT] = (r == J) ? s : a[i][JT] * rinv;
+            }
+        }
+        Potf2Step<J + 1>::run(a, tx, ty, col_offset, info, colbuf);
     }
 };
 template <>
 struct Potf2Step<64> {
-    static __device__ __forceinline__ void run(double (&)[64], int, int64_t, int64_t*) {}
+    static __device__ __forceinline__ void run(double (&)[4][4], int, int, int64_t, int64_t*, double*) {}
 };
 
-__global__ __launch_bounds__(64) void potf2_64_kernel(double* A, int64_t ld, int64_t col_offset,
-                                                       int64_t* info) {
-    const int lane = threadIdx.x;
-    double a[64];
-    double* row = A + (int64_t)lane * ld;
+__global__ __launch_bounds__(256) void potf2_64_kernel(double* A, int64_t ld, int64_t col_offset,
+                                                        int64_t* info) {
+    __shared__ __attribute__((aligned(16))) double colbuf[128];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    double a[4][4];
 #pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        const d2 v = *reinterpret_cast<const d2*>(row + c);
-        a[c] = v.x;
-        a[c + 1] = v.y;
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+            a[i][jj] = (i >= jj) ? A[(int64_t)(ty + 16 * i) * ld + tx + 16 * jj] : 0.0;
+    if (tx == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) colbuf[ty + 16 * i] = a[i][0];
     }
-    Potf2Step<0>::run(a, lane, col_offset, info);
-    // store the lower part of the row (columns <= lane); pairs straddling the
-    // diagonal keep the old upper element
+    Potf2Step<0>::run(a, tx, ty, col_offset, info, colbuf);
+    // store the lower triangle
 #pragma unroll
-    for (int c = 0; c < 64; c += 2) {
-        if (c + 1 <= lane) {
-            *reinterpret_cast<d2*>(row + c) = d2{a[c], a[c + 1]};
-        } else if (c == lane) {
-            row[c] = a[c];
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj <= i; ++jj) {
+            const int r = ty + 16 * i, c = tx + 16 * jj;
+            if (c <= r) A[(int64_t)r * ld + c] = a[i][jj];
         }
-    }
 }
 
 hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_offset,
                            int64_t* info_dev) {
-    hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(64), 0, s, A, ld, col_offset, info_dev);
+    hipLaunchKernelGGL(potf2_64_kernel, dim3(1), dim3(256), 0, s, A, ld, col_offset, info_dev);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// trsm_rlt64: X (m x 64) <- X * L^-T by forward substitution along each row:
-//   x[c] = (x[c] - sum_{k<c} x[k] * L[c][k]) / L[c][c]
-// One lane per row of X; L sits in LDS and is read as wave-wide broadcasts.
-// The division is a multiplication with 1/L[c][c] (one true division per
-// column per block).
+// trsm_rlt64: X (m x 64) <- X * L^-T by substitution along each row, right-looking:
+//   x[c] *= 1/L[c][c];  then  x[c'] -= x[c] * L[c'][c]  for every c' > c
+// (independent FMAs, so the dependent chain is 64 multiply+FMA steps, not 2016).
+// One lane per row of X; L^T sits in LDS (column c of L contiguous) and is
+// read as wave-wide 16-byte broadcasts.  One true division per column per block.
 // ---------------------------------------------------------------------------
 constexpr int TRSM_THREADS = 128;
 
 template <int C>
 struct TrsmStep {
-    static __device__ __forceinline__ void run(double (&x)[64], const double* Ls, const double* rd) {
-        double s = x[C];
+    static __device__ __forceinline__ void run(double (&x)[64], const double* Lt, const double* rd) {
+        const double xc = x[C] * rd[C];
+        x[C] = xc;
+        if constexpr (C < 63) {
+            constexpr int C0 = (C + 1) & ~1;
+            const double* col = Lt + C * 64;     // col[c'] = L[c'][C]
 #pragma unroll
-        for (int k = 0; k < C; ++k) s = fma(-x[k], Ls[C * 64 + k], s);
-        x[C] = s * rd[C];
-        TrsmStep<C + 1>::run(x, Ls, rd);
+            for (int c = C0; c < 64; c += 2) {
+                const d2 lv = *reinterpret_cast<const d2*>(col + c);
+                if (c > C) x[c] = fma(-xc, lv.x, x[c]);
+                x[c + 1] = fma(-xc, lv.y, x[c + 1]);
+            }
+        }
+        TrsmStep<C + 1>::run(x, Lt, rd);
     }
 };
 template <>
@@ -107,14 +171,13 @@ struct TrsmStep<64> {
 
 __global__ __launch_bounds__(TRSM_THREADS) void trsm_rlt64_kernel(const double* L, int64_t ldl,
                                                                    double* X, int64_t ldx, int64_t m) {
-    __shared__ __attribute__((aligned(16))) double Ls[64 * 64];
+    __shared__ __attribute__((aligned(16))) double Lt[64 * 64];
     __shared__ double rd[64];
     const int tid = threadIdx.x;
-    // stage L (row-major 64 x 64), coalesced 16-byte pieces
-    for (int p = tid; p < 64 * 32; p += TRSM_THREADS) {
-        const int r = p >> 5, c2 = (p & 31) * 2;
-        const d2 v = *reinterpret_cast<const d2*>(L + (int64_t)r * ldl + c2);
-        *reinterpret_cast<d2*>(&Ls[r * 64 + c2]) = v;
+    // stage L transposed: Lt[c][r] = L[r][c]; global reads coalesced along c
+    for (int p = tid; p < 64 * 64; p += TRSM_THREADS) {
+        const int r = p >> 6, c = p & 63;
+        Lt[c * 64 + r] = (c <= r) ? L[(int64_t)r * ldl + c] : 0.0;
     }
     if (tid < 64) rd[tid] = 1.0 / L[(int64_t)tid * ldl + tid];
     __syncthreads();
@@ -128,7 +191,7 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_rlt64_kernel(const double* 
         x[c] = v.x;
         x[c + 1] = v.y;
     }
-    TrsmStep<0>::run(x, Ls, rd);
+    TrsmStep<0>::run(x, Lt, rd);
 #pragma unroll
     for (int c = 0; c < 64; c += 2) *reinterpret_cast<d2*>(xr + c) = d2{x[c], x[c + 1]};
 }
