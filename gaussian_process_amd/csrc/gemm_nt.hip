@@ -42,7 +42,9 @@ struct GemmDev {
     int SM, SN;        // super-tiles in M, N
     int tri;           // triangular super-tile enumeration
     int nsuper;
-    int stagger;       // first-wave blocks start de-phased (see kernel)
+    int stagger;       // start delay of odd-slot first-wave workgroups (s_sleep units), 0 = off
+    int stagger_rule;  // experiment: how the delayed half is chosen
+    int dbg;           // timing-only ablations (gpmi_probe_gemm): results are wrong when non-zero
 };
 
 __device__ __forceinline__ bool map_tile(const GemmDev& p, int& ti, int& tj) {
@@ -68,8 +70,9 @@ __device__ __forceinline__ bool map_tile(const GemmDev& p, int& ti, int& tj) {
     return ti < p.Tm && tj < p.Tn;
 }
 
-template <int NI>
+template <int NI, bool DBG>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
+    const int dbg = DBG ? p.dbg : 0;   // ablation bits exist only in the probe instantiation
     constexpr int TM = 128;
     constexpr int TN = 32 * NI;
     constexpr int A_SLOTS = KP * TM;          // 16-byte slots per stage
@@ -90,16 +93,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
         if (min_col > max_row + p.diag_off) return;
     }
 
-    // Every tile of a launch runs the same number of K steps, so without help all
-    // resident blocks reach their HBM-heavy epilogue (C tile read-modify-write)
-    // at the same moment while the memory system idles during the main loops.
-    // The blocks of the first residency wave therefore start after 0..7 eighths
-    // of a tile time; their successors inherit the phase (a block starts when a
-    // slot frees).  Speed only: any dispatch order gives the same results.
+    // The two workgroups that share a CU start together and, sharing each SIMD's
+    // matrix pipe evenly, stay in lockstep: both reach the end-of-step LDS refill
+    // (ds_write, barrier, first fragment reads) at the same time and the pipe
+    // idles.  The workgroup that landed in the odd wave slot of its SIMD therefore
+    // starts half a K step late; successors inherit the offset (a workgroup starts
+    // when a slot frees).  Speed only: results do not depend on placement.
     if (p.stagger && blockIdx.x < 512) {
-        const unsigned phase = (blockIdx.x * 0x9E3779B1u) >> 29;     // 0..7
-        const int naps = (int)(phase * (unsigned)p.nchunks) >> 3;    // x 8128 cycles each
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        // HW_REG_HW_ID (id 4), WAVE_ID field [3:0]: hwreg(4, 0, 4)
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
+        unsigned wslot = __builtin_amdgcn_readfirstlane(slot);
+        if (p.stagger_rule == 1) wslot = blockIdx.x >> 8;        // assume b and b+256 share a CU
+        else if (p.stagger_rule == 2) wslot = blockIdx.x >> 3;   // assume b and b+8 share a CU
+        if (wslot & 1)
+            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);   // x 64 cycles
     }
 
     const int tid = threadIdx.x;
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     const int fr = lane & 15;
     const int fg = lane >> 4;
 
-    const double* Ag = p.A + (int64_t)ti * TM * p.lda;
-    const double* Bg = p.B + (int64_t)tj * TN * p.ldb;
+    const double* Ag = p.A + ((dbg & 16) ? 0 : (int64_t)ti * TM * p.lda);
+    const double* Bg = p.B + ((dbg & 16) ? 0 : (int64_t)tj * TN * p.ldb);
 
     // staging assignment: piece = tid + 256*i -> row = piece>>3, kp = piece&7
     const int st_kp = tid & 7;
@@ -157,7 +164,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     const int nch = p.nchunks;
     for (int c = 0; c < nch; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nch) load_stage(c + 1);
+        // branch-free body (one scheduling region): the last step re-loads its own
+        // chunk and refills a stage nobody reads any more
+        if (!(dbg & 1)) load_stage(c + 1 < nch ? c + 1 : c);
         const d2* sa = smem + buf * STAGE;
         const d2* sb = sa + A_SLOTS;
 #pragma unroll
@@ -173,42 +182,59 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+            // the refill of the other LDS stage (last read before the previous barrier)
+            // rides in the shadow of the step's last MFMAs; with a branch-free body the
+            // compiler also sinks half of those MFMAs below the barrier, so the barrier
+            // wait overlaps matrix work
+            if (t == 1 && !(dbg & 3)) write_stage(buf ^ 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nch) write_stage(buf ^ 1);
-        __syncthreads();
+        if (!(dbg & 2)) __syncthreads();
     }
 
-    // epilogue: D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = 4*v + (lane>>4)
+    // D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = 4*v + (lane>>4)
     double* Cg = p.C + ((int64_t)ti * TM + wr) * p.ldc + (int64_t)tj * TN + wc;
-    if (p.mode == 0) {
+    auto c_ptr = [&](int i, int j, int v) { return Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr; };
+    if ((DBG && (dbg & 8))) {
+        double t = 0.;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
+            for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456) Cg[0] = t;
+    } else if (p.mode == 0 && !(dbg & 4)) {
+        // C -= acc in 16-row bands: all loads of a band are issued before its first
+        // store (a load behind a possibly aliasing store would otherwise wait for it:
+        // 64 serial memory round trips per lane)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double cv[NI][4];
+#pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    double* ptr = Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr;
-                    *ptr = *ptr - acc[i][j][v];
-                }
+                for (int v = 0; v < 4; ++v) cv[j][v] = *c_ptr(i, j, v);
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) *c_ptr(i, j, v) = cv[j][v] - acc[i][j][v];
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    double* ptr = Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr;
-                    *ptr = acc[i][j][v];
-                }
+                for (int v = 0; v < 4; ++v) *c_ptr(i, j, v) = acc[i][j][v];
     }
 }
 
-int g_gemm_stagger = 1;
+int g_gemm_stagger = 0;    // s_sleep units (x 64 cycles); 0 disables (no measurable effect so far)
+int g_gemm_dbg = 0;
+int g_gemm_stagger_rule = 0;
 
 static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
     p.C = a.C; p.A = a.A; p.B = a.B;
@@ -235,7 +261,10 @@ static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
     p.logS = (p.S == 8) ? 3 : (p.S == 4) ? 2 : (p.S == 2) ? 1 : 0;
     nblocks = ((p.nsuper + 7) / 8) * 8 * p.S * p.S;
     // stagger only pays when the launch runs several residency waves of long tiles
-    p.stagger = (g_gemm_stagger && p.nchunks >= 16 && (int64_t)p.Tm * p.Tn >= 2048) ? 1 : 0;
+    p.dbg = g_gemm_dbg;
+    p.stagger_rule = g_gemm_stagger_rule;
+    // half a K step = 32 MFMAs x 64 cycles x 2 waves per SIMD; s_sleep counts 64-cycle units
+    p.stagger = (p.nchunks >= 8 && (int64_t)p.Tm * p.Tn >= 1024) ? g_gemm_stagger : 0;
 }
 
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
@@ -248,14 +277,16 @@ hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
         constexpr size_t lds = 2 * (KP * 128 + KP * 128) * 16;
         static bool attr = false;
         if (!attr) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        hipLaunchKernelGGL(gemm_nt_kernel<4>, dim3(nblocks), dim3(256), lds, s, p);
+        if (p.dbg) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), dim3(nblocks), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<4, false>), dim3(nblocks), dim3(256), lds, s, p);
     } else {
         plan(a, 64, p, nblocks);
         constexpr size_t lds = 2 * (KP * 128 + KP * 64) * 16;
-        hipLaunchKernelGGL(gemm_nt_kernel<2>, dim3(nblocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<2, false>), dim3(nblocks), dim3(256), lds, s, p);
     }
     return hipGetLastError();
 }

@@ -389,7 +389,7 @@ int gpmi_ctx_create(int device, gpmi_ctx** out) {
     if ((env = getenv("GPMI_NB"))) c->nb = std::max<int64_t>(128, atoll(env) / 128 * 128);
     if ((env = getenv("GPMI_LD_PAD"))) c->ld_pad = std::max<int64_t>(0, atoll(env) / 2 * 2);
     if ((env = getenv("GPMI_LOOKAHEAD"))) c->lookahead = atoi(env) ? 1 : 0;
-    if ((env = getenv("GPMI_GEMM_STAGGER"))) g_gemm_stagger = atoi(env) ? 1 : 0;
+    if ((env = getenv("GPMI_GEMM_STAGGER"))) g_gemm_stagger = std::min(127, std::max(0, atoi(env)));
     *out = c;
     return GPMI_OK;
 }
@@ -420,8 +420,11 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_stagger_rule")) {
+        g_gemm_stagger_rule = (int)value;
     } else if (!strcmp(name, "gemm_stagger")) {
-        g_gemm_stagger = value ? 1 : 0;
+        if (value < 0 || value > 127) return fail_arg("gemm_stagger must be 0..127 (s_sleep units)");
+        g_gemm_stagger = (int)value;
     } else {
         return fail_arg("gpmi_set_option: unknown option");
     }
@@ -696,26 +699,94 @@ int gpmi_get_timers(gpmi_ctx* c, double* stage_ms, int count) {
     return GPMI_OK;
 }
 
-int gpmi_probe_mfma_f64(gpmi_ctx* c, double* tflops) {
-    if (!c || !tflops) return fail_arg("gpmi_probe_mfma_f64: null argument");
+// out[0] = TFLOP/s, out[1] = shader clock (GHz) held during the loop,
+// out[2] = shader cycles per MFMA per SIMD
+int gpmi_probe_mfma_f64_ex(gpmi_ctx* c, int blocks_per_cu, int nacc, int iters, double* out) {
+    if (!c || !out) return fail_arg("gpmi_probe_mfma_f64_ex: null argument");
+    if (blocks_per_cu < 1 || blocks_per_cu > 8 || iters < 1) return fail_arg("gpmi_probe_mfma_f64_ex: bad argument");
+    if (nacc != 4 && nacc != 8 && nacc != 16) return fail_arg("gpmi_probe_mfma_f64_ex: nacc must be 4, 8 or 16");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->red.ensure(16 * 8));
     hipStream_t s = c->stream;
-    const int iters = 4096, blocks = 256 * 2;   // 2 blocks of 4 waves per CU
-    HIP_TRY(launch_probe_mfma(s, c->red.as<double>(), 64, blocks));   // warm-up
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount * blocks_per_cu;
+    double* sink = c->red.as<double>();
+    unsigned long long* clk = reinterpret_cast<unsigned long long*>(sink + 8);
+    HIP_TRY(launch_probe_mfma(s, sink, 64, blocks, nacc, clk));   // warm-up
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, s));
-    HIP_TRY(launch_probe_mfma(s, c->red.as<double>(), iters, blocks));
+    HIP_TRY(launch_probe_mfma(s, sink, iters, blocks, nacc, clk));
     HIP_TRY(hipEventRecord(b, s));
     HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    const double flops = (double)blocks * 4 /*waves*/ * iters * 8 /*mfma*/ * 2048.0;
-    *tflops = flops / (ms * 1e-3) / 1e12;
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost));
+    const double n_mfma_wave = (double)iters * nacc;
+    out[0] = (double)blocks * 4 * n_mfma_wave * 2048.0 / (ms * 1e-3) / 1e12;
+    out[1] = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.;      // s_memrealtime ticks at 100 MHz
+    out[2] = (double)h[0] / (n_mfma_wave * blocks_per_cu);           // waves per SIMD = blocks per CU
     return GPMI_OK;
+}
+
+int gpmi_probe_mfma_f64(gpmi_ctx* c, double* tflops) {
+    if (!tflops) return fail_arg("gpmi_probe_mfma_f64: null argument");
+    double out[3];
+    int rc = gpmi_probe_mfma_f64_ex(c, 2, 16, 2048, out);
+    if (rc == GPMI_OK) *tflops = out[0];
+    return rc;
+}
+
+// Timing of one GEMM launch shape on scratch buffers (results discarded).
+// variant: ablation bits (1: no global loads in the K loop, 2: no LDS writes / barriers,
+// 4: epilogue without the C read, 8: no epilogue).  out[0] = TFLOP/s over computed tiles,
+// out[1] = ms per launch.
+int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps,
+                    double* out) {
+    if (!c || !out) return fail_arg("gpmi_probe_gemm: null argument");
+    if (M <= 0 || N <= 0 || K <= 0 || M % TILE || N % IB || K % 16 || reps < 1)
+        return fail_arg("gpmi_probe_gemm: M%128, N%64, K%16 must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t ldc = N + c->ld_pad, ldk = K + c->ld_pad;
+    DevBuf C, A, B;
+    int rc = GPMI_OK;
+    hipError_t e;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    do {
+        if ((e = C.ensure((size_t)M * ldc * 8)) != hipSuccess || (e = A.ensure((size_t)M * ldk * 8)) != hipSuccess ||
+            (e = B.ensure((size_t)N * ldk * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
+        (void)hipMemsetAsync(C.p, 0, (size_t)M * ldc * 8, s);
+        (void)launch_fill_rows(s, A.as<double>(), ldk, M, K, 0.001);
+        (void)launch_fill_rows(s, B.as<double>(), ldk, N, K, -0.002);
+        GemmArgs g;
+        g.C = C.as<double>(); g.A = A.as<double>(); g.B = B.as<double>();
+        g.ldc = ldc; g.lda = g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = 0;
+        g_gemm_dbg = variant;
+        e = launch_gemm_nt(s, g);
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        (void)hipEventRecord(ea, s);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_gemm_nt(s, g);
+        (void)hipEventRecord(eb, s);
+        hipError_t e2 = hipEventSynchronize(eb);
+        g_gemm_dbg = 0;
+        if (e != hipSuccess) { rc = fail_runtime(e, "gemm launch"); break; }
+        if (e2 != hipSuccess) { rc = fail_runtime(e2, "gemm sync"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ea, eb);
+        out[1] = ms / reps;
+        out[0] = gemm_nt_flops(g) / (out[1] * 1e-3) / 1e12;
+    } while (0);
+    g_gemm_dbg = 0;
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    (void)hipStreamSynchronize(s);
+    C.release(); A.release(); B.release();
+    return rc;
 }
 
 int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {

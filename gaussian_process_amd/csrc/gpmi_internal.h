@@ -24,6 +24,8 @@ struct GemmArgs {
     int64_t diag_off;
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
+extern int g_gemm_dbg;       // timing-only ablation bits for gpmi_probe_gemm (0 in production)
+extern int g_gemm_stagger_rule;
 extern int g_gemm_stagger;   // tuning switch (GPMI_GEMM_STAGGER / option "gemm_stagger")
 // number of tiles the launch actually computes (for flop accounting)
 double gemm_nt_flops(const GemmArgs& a);
@@ -71,7 +73,8 @@ hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0
                           int64_t c0, int64_t c1, double* out, int lower_only);
 
 // ---- probes ----------------------------------------------------------------
-hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks);
+hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks, int nacc,
+                             unsigned long long* clk);
 hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles);
 
 }  // namespace gpmi

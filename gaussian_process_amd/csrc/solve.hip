@@ -179,24 +179,35 @@ hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0
 // ---- probes ----------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void probe_mfma_kernel(double* sink, int iters) {
-    d4 acc[8];
+template <int NACC>
+__global__ __launch_bounds__(256) void probe_mfma_kernel(double* sink, int iters, unsigned long long* clk) {
+    d4 acc[NACC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] = d4{0., 0., 0., 0.};
-    double a = 1.0 + threadIdx.x * 1e-3, b = 0.5 + threadIdx.x * 2e-3;
+    for (int i = 0; i < NACC; ++i) acc[i] = d4{0., 0., 0., 0.};
+    // bounded, sign-varying operands (random-ish mantissas: realistic switching power)
+    double a = 1.0 + (threadIdx.x * 37 % 101) * 1e-2, b = ((threadIdx.x & 1) ? -0.5 : 0.5) + threadIdx.x * 3e-4;
+    const unsigned long long t0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < NACC; ++i)
             acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+        a = -a;
     }
+    const unsigned long long t1 = clock64(), w1 = wall_clock64();
     double s = 0.;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
     if (s == 123.456) sink[0] = s;   // keep the loop alive
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
-hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks) {
-    hipLaunchKernelGGL(probe_mfma_kernel, dim3(blocks), dim3(256), 0, s, sink, iters);
+hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks, int nacc,
+                             unsigned long long* clk) {
+    switch (nacc) {
+        case 4: hipLaunchKernelGGL(probe_mfma_kernel<4>, dim3(blocks), dim3(256), 0, s, sink, iters, clk); break;
+        case 16: hipLaunchKernelGGL(probe_mfma_kernel<16>, dim3(blocks), dim3(256), 0, s, sink, iters, clk); break;
+        default: hipLaunchKernelGGL(probe_mfma_kernel<8>, dim3(blocks), dim3(256), 0, s, sink, iters, clk); break;
+    }
     return hipGetLastError();
 }
 

@@ -58,6 +58,18 @@ class GPContext:
         check(self._lib.gpmi_probe_mfma_f64(self._h, C.byref(v)))
         return v.value
 
+    def probe_mfma_f64_ex(self, blocks_per_cu=2, nacc=16, iters=2048):
+        """-> (TFLOP/s, shader clock GHz, cycles per MFMA per SIMD)"""
+        out = np.zeros(3)
+        check(self._lib.gpmi_probe_mfma_f64_ex(self._h, blocks_per_cu, nacc, iters, ptr(out)))
+        return tuple(out)
+
+    def probe_gemm(self, M, N, K, lower=0, variant=0, reps=3):
+        """-> (TFLOP/s, ms per launch) of the trailing-update GEMM kernel on scratch buffers"""
+        out = np.zeros(2)
+        check(self._lib.gpmi_probe_gemm(self._h, M, N, K, lower, variant, reps, ptr(out)))
+        return tuple(out)
+
     def probe_hbm_write(self, nbytes=1 << 30):
         v = C.c_double()
         check(self._lib.gpmi_probe_hbm_write(self._h, int(nbytes), C.byref(v)))

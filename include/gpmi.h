@@ -133,6 +133,14 @@ int gpmi_sync(gpmi_ctx* ctx);
 /* fp64 MFMA issue rate: returns achieved TFLOP/s of a register-only
  * v_mfma_f64_16x16x4_f64 loop over the whole chip. */
 int gpmi_probe_mfma_f64(gpmi_ctx* ctx, double* tflops);
+/* same loop with blocks_per_cu workgroups of 4 waves per CU and nacc (4, 8, 16)
+ * independent accumulators per wave; out[0] = TFLOP/s, out[1] = shader clock in
+ * GHz held during the loop, out[2] = shader cycles per MFMA per SIMD */
+int gpmi_probe_mfma_f64_ex(gpmi_ctx* ctx, int blocks_per_cu, int nacc, int iters, double* out);
+/* one launch shape of the trailing-update GEMM on scratch buffers; variant = timing-only
+ * ablation bits (0 = the production kernel); out[0] = TFLOP/s, out[1] = ms per launch */
+int gpmi_probe_gemm(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps,
+                    double* out);
 /* streaming-store bandwidth (GB/s) over `bytes` of device memory */
 int gpmi_probe_hbm_write(gpmi_ctx* ctx, int64_t bytes, double* gbps);
 
