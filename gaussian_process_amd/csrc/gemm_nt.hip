@@ -42,6 +42,8 @@ struct GemmDev {
     int SM, SN;        // super-tiles in M, N
     int tri;           // triangular super-tile enumeration
     int nsuper;
+    const int32_t* row_ncols;
+    int row_block_tiles;
     int stagger;       // start delay of odd-slot first-wave workgroups (s_sleep units), 0 = off
     int stagger_rule;  // experiment: how the delayed half is chosen
     int dbg;           // timing-only ablations (gpmi_probe_gemm): results are wrong when non-zero
@@ -91,6 +93,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
         const int64_t min_col = (int64_t)tj * TN;
         const int64_t max_row = (int64_t)ti * TM + TM - 1;
         if (min_col > max_row + p.diag_off) return;
+    }
+    if (p.row_ncols) {
+        if ((int64_t)tj * TN >= p.row_ncols[ti / p.row_block_tiles]) return;
     }
 
     // The two workgroups that share a CU start together and, sharing each SIMD's
@@ -245,6 +250,8 @@ static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
     p.mode = a.mode;
     p.lower = a.lower;
     p.diag_off = a.diag_off;
+    p.row_ncols = a.row_ncols;
+    p.row_block_tiles = a.row_block_tiles > 0 ? a.row_block_tiles : 1;
     // triangular super-tile enumeration only for square tiles on the diagonal
     // (and only when the region is not a tall skinny strip, where most
     // triangular super-tiles would be empty)

@@ -872,6 +872,28 @@ int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_d
     return GPMI_OK;
 }
 
+int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                            const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                            const int32_t* row_ncols_dev, int64_t row_block_rows) {
+    if (!C_dev || !A_dev || !B_dev || !row_ncols_dev) return fail_arg("gpmi_dev_gemm_nt_rowmap: null pointer");
+    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2 ||
+        row_block_rows <= 0 || row_block_rows % TILE)
+        return fail_arg("gpmi_dev_gemm_nt_rowmap: M%128, N%64, K%16, row_block_rows%128 must be 0");
+    GemmArgs g;
+    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = 0; g.diag_off = 0;
+    g.row_ncols = row_ncols_dev; g.row_block_tiles = (int)(row_block_rows / TILE);
+    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
+    return GPMI_OK;
+}
+
+int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
+                           int64_t nx, double* out2_dev) {
+    if (!out2_dev) return fail_arg("gpmi_dev_logdiag_sumsq: null output");
+    HIP_TRY(launch_logdiag_sumsq((hipStream_t)stream, A_dev, ld, n, x_dev, nx, out2_dev));
+    return GPMI_OK;
+}
+
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
                       const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
     if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");

@@ -22,6 +22,11 @@ struct GemmArgs {
     int mode;
     int lower;
     int64_t diag_off;
+    // optional: row_ncols[ti / row_block_tiles] = number of leading columns of C that
+    // the 128-row tile band ti updates (row-block cyclic storage: a rank's stacked
+    // row blocks reach different distances to the right); device pointer or null
+    const int32_t* row_ncols = nullptr;
+    int row_block_tiles = 1;
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
 extern int g_gemm_dbg;       // timing-only ablation bits for gpmi_probe_gemm (0 in production)
@@ -62,6 +67,9 @@ hipError_t launch_row_dots(hipStream_t s, const double* V, int64_t ld, int64_t n
 // out[0] = sum_{i<n} log(A[i*(ld+1)]), out[1] = sum_{i<n} m[i]^2 (deterministic)
 hipError_t launch_lml_reduce(hipStream_t s, const double* A, int64_t ld, const double* m,
                              int64_t n, double* out2);
+// out2[0] = sum_{i<n} log(A[i*(ld+1)]) (0 if A null), out2[1] = sum_{i<nx} x[i]^2 (0 if x null)
+hipError_t launch_logdiag_sumsq(hipStream_t s, const double* A, int64_t ld, int64_t n, const double* x,
+                                int64_t nx, double* out2);
 // backward substitution  L^T x = b  (x overwrites b); n multiple of 64
 hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b, int64_t n);
 // fill helpers

@@ -79,6 +79,24 @@ hipError_t launch_lml_reduce(hipStream_t s, const double* A, int64_t ld, const d
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(1024) void logdiag_sumsq_kernel(const double* A, int64_t ld, int64_t n,
+                                                              const double* x, int64_t nx, double* out2) {
+    __shared__ double sh[32];
+    double a = 0., b = 0.;
+    if (A)
+        for (int64_t i = threadIdx.x; i < n; i += 1024) a += log(A[i * (ld + 1)]);
+    if (x)
+        for (int64_t i = threadIdx.x; i < nx; i += 1024) b = fma(x[i], x[i], b);
+    block_reduce2<1024>(a, b, sh);
+    if (threadIdx.x == 0) { out2[0] = a; out2[1] = b; }
+}
+
+hipError_t launch_logdiag_sumsq(hipStream_t s, const double* A, int64_t ld, int64_t n, const double* x,
+                                int64_t nx, double* out2) {
+    hipLaunchKernelGGL(logdiag_sumsq_kernel, dim3(1), dim3(1024), 0, s, A, ld, n, x, nx, out2);
+    return hipGetLastError();
+}
+
 // ---- backward substitution L^T x = b (reference: GP_regression.py:140) --------
 // Blocks of 64 unknowns from the bottom up.  diag kernel: one wavefront solves
 // L_jj^T x_j = b_j column-oriented (x_r known -> b_c -= L[r][c] * x_r, c < r);

@@ -1,0 +1,355 @@
+"""Multi-GPU GP fit + predict: the N x N covariance row-block partitioned (block-cyclic)
+over the ranks of one node, one process per GPU, collectives through
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+Reference path: GP_regression.py:126-148 / tune_hyperparms_regression.py:306-312 (the
+reference itself is single-process NumPy; SURVEY.md section 8e is the design this follows).
+
+Layout.  NB-row blocks of K + sI; global block b lives on rank b % G, stacked in
+increasing b in that rank's local matrix A (rows) x (Np + pad) -- row-major, so the
+rank holds whole rows of L.  One extra 128-row block carries y (rank T % G): the
+factorisation sweeps it like any other row block, so it ends as m = L^-1 y.
+
+Right-looking step k (block column k):
+  owner: Cholesky of the diagonal block -> L_kk         [gpmi_dev_potrf_block]
+  broadcast L_kk (NB x NB)                                [RCCL broadcast]
+  every rank: its rows below k  <-  rows * L_kk^-T        [gpmi_dev_trsm_block]
+  all-gather of the panel column (each rank's rows)       [RCCL all_gather]
+  every rank: trailing update of its own rows, one launch  [gpmi_dev_gemm_nt_rowmap]
+Predict: v^T = K_s^T L^-T with the COLUMN blocks of v^T distributed like the row
+blocks of L; per step the owner solves its block, broadcasts it, and every rank
+updates its own column blocks; mean / variance are ordered sums of per-rank partial
+row dots.  No collective carries more than the panel column / one solved block.
+
+torch is used for device memory, strided copies, streams and torch.distributed only;
+all arithmetic goes through the C-ABI block primitives (`HipBlockOps`).  The driver
+takes the primitives as an object so that the CPU tests (gloo, world_size 2) can run
+the same schedule on NumPy stand-ins defined under tests/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check
+
+YB = 128                  # rows of the y block (one tile)
+INT64_MAX = (1 << 63) - 1
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class HipBlockOps:
+    """Block primitives on torch CUDA tensors through libgpmi355x.so (gpmi_dev_*).
+    Views must be float64 with unit column stride; ld = view.stride(0)."""
+
+    def __init__(self, device_index):
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device_index)
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    @staticmethod
+    def _ld(t):
+        assert t.dtype == torch.float64 and (t.dim() == 1 or t.stride(-1) == 1)
+        return t.stride(0) if t.dim() == 2 else t.shape[0]
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def rbf_rows(self, X, N, d, row0, nrows, ncols, sigma, ell, noise_var, out):
+        check(self.lib.gpmi_dev_rbf_rows(self._stream(), self._p(X), N, d, row0, nrows, ncols,
+                                         float(sigma), float(ell), float(noise_var), self._p(out), self._ld(out)))
+
+    def rbf_cross(self, Xs, n, Xcols, ncols_real, d, nrows, ncols, sigma, ell, out):
+        """out[i][j] = k(Xs[i], Xcols[j]); rows >= n and cols >= ncols_real are zero."""
+        check(self.lib.gpmi_dev_rbf_cross(self._stream(), self._p(Xs), n, self._p(Xcols), max(ncols_real, 0), d,
+                                          0, nrows, ncols, float(sigma), float(ell), self._p(out), self._ld(out)))
+
+    def potrf_block(self, A, col_offset, info):
+        check(self.lib.gpmi_dev_potrf_block(self._stream(), self._p(A), self._ld(A), A.shape[0], col_offset,
+                                            self._p(info)))
+
+    def trsm_block(self, L, X):
+        check(self.lib.gpmi_dev_trsm_block(self._stream(), self._p(L), self._ld(L), self._p(X), self._ld(X),
+                                           X.shape[0], X.shape[1]))
+
+    def gemm_nt(self, Cm, A, B):
+        check(self.lib.gpmi_dev_gemm_nt(self._stream(), self._p(Cm), self._ld(Cm), self._p(A), self._ld(A),
+                                        self._p(B), self._ld(B), Cm.shape[0], Cm.shape[1], A.shape[1], 0, 0))
+
+    def gemm_nt_rowmap(self, Cm, A, B, row_ncols, row_block_rows):
+        check(self.lib.gpmi_dev_gemm_nt_rowmap(self._stream(), self._p(Cm), self._ld(Cm), self._p(A), self._ld(A),
+                                               self._p(B), self._ld(B), Cm.shape[0], Cm.shape[1], A.shape[1],
+                                               C.c_void_p(row_ncols.data_ptr()), row_block_rows))
+
+    def logdiag_sumsq(self, A, n, x, nx, out2):
+        check(self.lib.gpmi_dev_logdiag_sumsq(self._stream(), self._p(A) if A is not None else None,
+                                              self._ld(A) if A is not None else 0, n,
+                                              self._p(x) if x is not None else None, nx, self._p(out2)))
+
+    def row_dots(self, V, ncols, m, dot, sq):
+        check(self.lib.gpmi_dev_row_dots(self._stream(), self._p(V), self._ld(V), V.shape[0], ncols,
+                                         self._p(m), self._p(dot), self._p(sq)))
+
+    def sync(self):
+        torch.cuda.synchronize(self.device)
+
+
+class DistGP:
+    """Row-block cyclic GP fit / predict over the ranks of `group` (default: WORLD)."""
+
+    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DistGP needs torch.distributed (init_process_group) -- one rank per GPU")
+        if nb <= 0 or nb % 128:
+            raise ValueError("nb must be a positive multiple of 128")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.G = dist.get_world_size(group)
+        self.ops = ops if ops is not None else HipBlockOps(device_index)
+        self.dev = self.ops.device
+        self.NB = int(nb)
+        self.ld_pad = int(ld_pad) // 2 * 2
+        self.have_factor = False
+        self.have_test = False
+        self.stage_ms = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _src(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def _lstart(self, k, r=None):
+        """first local block index of rank r whose global block index is > k"""
+        r = self.rank if r is None else r
+        return 0 if k < r else (k - r) // self.G + 1
+
+    def _nblocks(self, r):
+        return len(range(r, self.T, self.G))
+
+    def _tensor(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    # ------------------------------------------------------------------ data
+    def set_train(self, X, y):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+        if X.ndim != 2 or y.shape[0] != X.shape[0]:
+            raise ValueError("X_train must be (N, d) and y_train (N,)")
+        self.N, self.d = X.shape
+        NB, G = self.NB, self.G
+        self.Np = _round_up(self.N, NB)
+        self.T = self.Np // NB
+        self.my_blocks = list(range(self.rank, self.T, G))
+        self.nloc = len(self.my_blocks)
+        self.ry = self.T % G                         # rank that carries the y block
+        self.yrow = self.nloc * NB if self.rank == self.ry else None
+        self.rows = self.nloc * NB + (YB if self.rank == self.ry else 0)
+        self.ld = self.Np + self.ld_pad
+        # X, y replicated (N*(d+1)*8 bytes); broadcast from rank 0 so every rank factors the same data
+        self.X = torch.from_numpy(X).to(self.dev)
+        self.y = torch.from_numpy(y).to(self.dev)
+        if G > 1:
+            dist.broadcast(self.X, src=self._src(0), group=self.group)
+            dist.broadcast(self.y, src=self._src(0), group=self.group)
+        self.A = self._tensor(max(self.rows, 1), self.ld)
+        self.Lkk = self._tensor(NB, NB)
+        cmax = max(self._nblocks(r) for r in range(G))
+        self.send = self._tensor(max(cmax, 1) * NB, NB)
+        self.recv = self._tensor(G * max(cmax, 1) * NB, NB)
+        self.Pfull = self._tensor(max(self.T - 1, 1) * NB, NB)
+        self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
+        self.red = self._tensor(max(self.nloc, 1) + 1, 2)
+        self.m = self._tensor(self.Np)
+        # per step: number of columns each 128-row band of my rows below block k updates
+        bands = NB // 128
+        tabs, offs = [], []
+        for k in range(self.T - 1):
+            ls = self._lstart(k)
+            offs.append(sum(len(t) for t in tabs))
+            t = []
+            for li in range(ls, self.nloc):
+                t += [(self.my_blocks[li] - k) * NB] * bands
+            if self.rank == self.ry:
+                t += [self.Np - (k + 1) * NB] * (YB // 128)
+            tabs.append(t)
+        flat = [v for t in tabs for v in t] or [0]
+        self.rowmap = torch.tensor(flat, dtype=torch.int32, device=self.dev)
+        self.rowmap_off = offs
+        self.rowmap_len = [len(t) for t in tabs]
+        self.have_factor = False
+        self.have_test = False
+
+    # ------------------------------------------------------------------ fit
+    def factorize(self, sigma, ell, noise_var):
+        """K + sI -> L (distributed), m = L^-1 y; returns the log-marginal-likelihood
+        (tune_hyperparms_regression.py:312) on every rank.  Raises LinAlgError on every
+        rank if a pivot is not positive."""
+        ops, NB, G, A = self.ops, self.NB, self.G, self.A
+        self.sigma, self.ell = float(sigma), float(ell)
+        self.have_factor = False
+        self.info.fill_(INT64_MAX)
+        # K + sI: my row blocks, lower part
+        for li, b in enumerate(self.my_blocks):
+            ops.rbf_rows(self.X, self.N, self.d, b * NB, NB, (b + 1) * NB, sigma, ell, noise_var,
+                         A[li * NB:(li + 1) * NB])
+        if self.yrow is not None:
+            A[self.yrow:self.yrow + YB, :self.Np].zero_()
+            A[self.yrow, :self.N].copy_(self.y)
+        for k in range(self.T):
+            owner = k % G
+            c0 = k * NB
+            if self.rank == owner:
+                li = k // G
+                diag = A[li * NB:(li + 1) * NB, c0:c0 + NB]
+                ops.potrf_block(diag, c0, self.info)
+                self.Lkk.copy_(diag)
+            if G > 1:
+                dist.broadcast(self.Lkk, src=self._src(owner), group=self.group)
+            ls = self._lstart(k)
+            r0 = ls * NB
+            m = self.rows - r0
+            if m > 0:
+                ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
+            if k == self.T - 1:
+                break
+            # panel column below block k, natural block order, on every rank
+            cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
+            cmax = max(cnts)
+            cnt = cnts[self.rank]
+            nbelow = self.T - k - 1
+            if G > 1:
+                send = self.send[:cmax * NB]
+                if cnt:
+                    send[:cnt * NB].copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
+                recv = self.recv[:G * cmax * NB]
+                dist.all_gather_into_tensor(recv, send, group=self.group)
+                P = self.Pfull[:nbelow * NB].view(nbelow, NB, NB)
+                R = recv.view(G, cmax, NB, NB)
+                for r in range(G):
+                    if cnts[r]:
+                        first = r + self._lstart(k, r) * G        # global index of r's first block below k
+                        P[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
+                Pfull = self.Pfull[:nbelow * NB]
+            else:
+                Pfull = A[r0:r0 + nbelow * NB, c0:c0 + NB]
+            if m > 0:
+                off, ln = self.rowmap_off[k], self.rowmap_len[k]
+                ops.gemm_nt_rowmap(A[r0:r0 + m, c0 + NB:self.Np], A[r0:r0 + m, c0:c0 + NB], Pfull,
+                                   self.rowmap[off:off + ln], 128)
+        # not-PD: smallest failing global column over all ranks
+        if G > 1:
+            dist.all_reduce(self.info, op=dist.ReduceOp.MIN, group=self.group)
+        info = int(self.info.item())
+        if info != INT64_MAX and info < self.N:
+            err = np.linalg.LinAlgError("Matrix is not positive definite")
+            err.bad_pivot = info + 1
+            raise err
+        # LML pieces: per-rank sum of log diag over owned blocks, m^T m on the y rank (fixed order)
+        self.red.zero_()
+        for li, b in enumerate(self.my_blocks):
+            ops.logdiag_sumsq(A[li * NB:(li + 1) * NB, b * NB:(b + 1) * NB], NB, None, 0, self.red[li])
+        if self.yrow is not None:
+            ops.logdiag_sumsq(None, 0, A[self.yrow], self.N, self.red[self.nloc])
+            self.m.copy_(A[self.yrow, :self.Np])
+        part = torch.stack([self.red[:max(self.nloc, 1), 0].sum(), self.red[self.nloc, 1]])
+        if G > 1:
+            allp = self._tensor(G * 2)
+            dist.all_gather_into_tensor(allp, part.contiguous(), group=self.group)
+            dist.broadcast(self.m, src=self._src(self.ry), group=self.group)
+        else:
+            allp = part
+        allp = allp.view(G, 2).cpu().numpy()
+        logsum = 0.0
+        for r in range(G):
+            logsum += float(allp[r, 0])
+        mtm = float(allp[self.ry, 1])
+        self.have_factor = True
+        return -.5 * mtm - logsum - self.N / 2.0 * math.log(2 * math.pi)
+
+    # ------------------------------------------------------------------ predict
+    def set_test(self, Xs):
+        Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+        if Xs.ndim != 2 or Xs.shape[1] != self.d:
+            raise ValueError("X_test must be (n, d) with the training d")
+        self.n = Xs.shape[0]
+        self.n_p = _round_up(self.n, 128)
+        self.Xs = torch.from_numpy(Xs).to(self.dev)
+        if self.G > 1:
+            dist.broadcast(self.Xs, src=self._src(0), group=self.group)
+        self.ldv = max(self.nloc, 1) * self.NB + self.ld_pad
+        self.V = self._tensor(self.n_p, self.ldv)
+        self.Xk = self._tensor(self.n_p, self.NB)
+        self.dots = self._tensor(2, self.n_p)
+        self.m_loc = self._tensor(max(self.nloc, 1) * self.NB)
+        self.have_test = True
+
+    def predict_resident(self, want_sd=True):
+        """mu = K_s^T alpha (as v^T m), var = sigma^2 - sum(v^2) (GP_regression.py:143-148)."""
+        if not self.have_factor:
+            raise ValueError("no factorisation resident (call factorize)")
+        if not self.have_test:
+            raise ValueError("no test set (call set_test)")
+        ops, NB, G, A, V = self.ops, self.NB, self.G, self.A, self.V
+        for li, b in enumerate(self.my_blocks):
+            ops.rbf_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, self.d, self.n_p, NB,
+                          self.sigma, self.ell, V[:, li * NB:(li + 1) * NB])
+            self.m_loc[li * NB:(li + 1) * NB].copy_(self.m[b * NB:(b + 1) * NB])
+        for k in range(self.T):
+            owner = k % G
+            c0 = k * NB
+            if self.rank == owner:
+                li = k // G
+                blk = V[:, li * NB:(li + 1) * NB]
+                ops.trsm_block(A[li * NB:(li + 1) * NB, c0:c0 + NB], blk)
+                if G > 1:
+                    self.Xk.copy_(blk)
+            if k == self.T - 1:
+                break
+            if G > 1:
+                dist.broadcast(self.Xk, src=self._src(owner), group=self.group)
+                Xk = self.Xk
+            else:
+                Xk = V[:, k * NB:(k + 1) * NB]
+            ls = self._lstart(k)
+            cnt = self.nloc - ls
+            if cnt > 0:
+                ops.gemm_nt(V[:, ls * NB:self.nloc * NB], Xk, A[ls * NB:self.nloc * NB, c0:c0 + NB])
+        self.dots.zero_()
+        if self.nloc:
+            ops.row_dots(V, self.nloc * NB, self.m_loc, self.dots[0], self.dots[1])
+        if G > 1:
+            alld = self._tensor(G * 2 * self.n_p)
+            dist.all_gather_into_tensor(alld, self.dots.view(-1), group=self.group)
+        else:
+            alld = self.dots
+        alld = alld.view(G, 2, self.n_p).cpu().numpy()
+        mu = np.zeros(self.n_p)
+        sq = np.zeros(self.n_p)
+        for r in range(G):                     # fixed order: bitwise reproducible
+            mu += alld[r, 0]
+            sq += alld[r, 1]
+        var = self.sigma ** 2 - sq[:self.n]
+        with np.errstate(invalid="ignore"):
+            out2 = np.sqrt(var) if want_sd else var
+        return mu[:self.n].copy(), out2
+
+    def predict(self, Xs, want_sd=True):
+        self.set_test(Xs)
+        return self.predict_resident(want_sd)
+
+    def fit(self, X, y, sigma, ell, noise_var):
+        self.set_train(X, y)
+        return self.factorize(sigma, ell, noise_var)
+
+    def timers(self):
+        return dict(self.stage_ms)

@@ -172,6 +172,16 @@ int gpmi_dev_trsm_block(void* stream, const double* L_dev, int64_t ldl, double* 
 int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
                      const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
                      int lower, int64_t diag_off);
+/* same, for a rank's STACKED row blocks (row-block cyclic storage): the 128-row tile
+ * bands of row block q (row_block_rows rows each) update only the leading
+ * row_ncols_dev[q] columns of C (int32 on the device) */
+int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                            const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                            const int32_t* row_ncols_dev, int64_t row_block_rows);
+/* out2[0] = sum_{i<n} log(A[i][i]) (skipped if A_dev is NULL), out2[1] = sum_{i<nx} x[i]^2
+ * (skipped if x_dev is NULL): the per-rank pieces of the log-marginal-likelihood */
+int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
+                           int64_t nx, double* out2_dev);
 /* out[i] = sum_j V[i][j]*m[j] ; out2[i] = sum_j V[i][j]^2  (partial sums over
  * the columns this rank owns), i < nrows, j < ncols */
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows,

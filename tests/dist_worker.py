@@ -1,0 +1,45 @@
+"""One rank of the multi-rank DistGP tests.  argv: rank world port backend device out_prefix N d n nb"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def main():
+    rank, world, port = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    backend, device, out = sys.argv[4], sys.argv[5], sys.argv[6]
+    N, d, n, nb = (int(v) for v in sys.argv[7:11])
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import gp_oracle as O
+    from gaussian_process_amd.dist import DistGP
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    if device == "cpu":
+        torch.set_num_threads(2)
+        from numpy_block_ops import NumpyBlockOps
+        gp = DistGP(nb=nb, ops=NumpyBlockOps())
+    else:
+        torch.cuda.set_device(0)           # all ranks share the one GPU of the test box
+        gp = DistGP(0, nb=nb)
+    X, y, Xs = O.synthetic_problem(N, d, n, seed=77)
+    lml = gp.fit(X, y, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
+    mu, var = gp.predict(Xs, want_sd=False)
+    lml2 = gp.factorize(1.3, 1.5 * np.sqrt(d / 8.0), 1e-3)        # refit on resident data
+    mu2, sd2 = gp.predict_resident(want_sd=True)
+    raised = 0
+    try:
+        gp.factorize(1.0, 2.0, -0.7)
+    except np.linalg.LinAlgError as e:
+        raised = int(e.bad_pivot)
+    np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""The multi-rank (row-block cyclic) driver: world_size-2 on CPU with gloo and NumPy
+stand-ins for the block primitives (runs anywhere), and world_size 2 / 3 on one GPU
+with the real HIP primitives (gpu marker; gloo moves the CUDA tensors)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return str(s.getsockname()[1])
+
+
+def _run(world, backend, device, tmp_path, N, d, n, nb):
+    port = _free_port()
+    out = str(tmp_path / "res")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world),
+                               port, backend, device, out, str(N), str(d), str(n), str(nb)], env=env)
+             for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [np.load(out + "_rank%d.npz" % r) for r in range(world)]
+
+
+def _check(res, oracle, N, d, n):
+    X, y, Xs = oracle.synthetic_problem(N, d, n, seed=77)
+    ell = 2.0 * np.sqrt(d / 8.0)
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, ell, 5e-4, use_c=False)
+    ref2 = oracle.fit_predict_feasible(X, Xs, y, 1.3, 1.5 * np.sqrt(d / 8.0), 1e-3, use_c=False)
+    K = oracle.RBF_kernel(X, X, 1.0, 2.0) - 0.7 * np.eye(N)
+    kbad = next(i for i in range(1, N + 1) if np.linalg.eigvalsh(K[:i, :i]).min() <= 0)
+    for r in res:
+        assert abs(r["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
+        assert np.max(np.abs(r["mu"] - ref["mu"])) <= 1e-9
+        assert np.max(np.abs(r["var"] - ref["var"])) <= 1e-10
+        assert abs(r["lml2"] - ref2["lml"]) <= 1e-10 * abs(ref2["lml"])
+        assert np.max(np.abs(r["mu2"] - ref2["mu"])) <= 1e-9
+        assert np.max(np.abs(r["sd2"] - np.sqrt(ref2["var"]))) <= 1e-9
+        assert int(r["raised"]) == kbad
+    for r in res[1:]:                      # every rank returns the same bits
+        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2"):
+            assert np.array_equal(r[key], res[0][key]), key
+
+
+@pytest.mark.parametrize("N,d,n,nb", [(700, 3, 50, 128), (300, 8, 140, 256)])
+def test_two_ranks_gloo_cpu(oracle, tmp_path, N, d, n, nb):
+    res = _run(2, "gloo", "cpu", tmp_path, N, d, n, nb)
+    _check(res, oracle, N, d, n)
+
+
+def test_three_ranks_gloo_cpu_uneven_blocks(oracle, tmp_path):
+    res = _run(3, "gloo", "cpu", tmp_path, 520, 2, 33, 128)      # 5 blocks over 3 ranks
+    _check(res, oracle, 520, 2, 33)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,N,d,n,nb", [(2, 1500, 8, 200, 256), (3, 2100, 8, 130, 128), (2, 4096, 8, 512, 512)])
+def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb):
+    res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb)
+    _check(res, oracle, N, d, n)
