@@ -72,7 +72,8 @@ struct gpmi_ctx {
     hipStream_t stream = nullptr;    // main stream: K build, trailing updates, reductions
     hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
     // options
-    int64_t nb = 512;       // outer block width of the Cholesky (multiple of 128)
+    int64_t nb = 0;         // outer block width of the Cholesky (multiple of 128); 0 = by size
+    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 24576 ? 1024 : 512); }
     int64_t ld_pad = 544;   // doubles added to every leading dimension
     int timing = 1;
     int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
@@ -204,7 +205,8 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
                             int64_t* info, bool account) {
     hipError_t e;
     hipStream_t sm = c->stream;
-    const bool la = c->lookahead && c->pstream && ncols > c->nb;
+    const int64_t NB = c->block(ncols);
+    const bool la = c->lookahead && c->pstream && ncols > NB;
     hipStream_t sp_ = la ? c->pstream : sm;
     const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
     const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
@@ -227,8 +229,8 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         }
         return er;
     };
-    for (int64_t k = 0; k < ncols; k += c->nb) {
-        const int64_t nb = std::min<int64_t>(c->nb, ncols - k);
+    for (int64_t k = 0; k < ncols; k += NB) {
+        const int64_t nb = std::min<int64_t>(NB, ncols - k);
         size_t sp = c->span_begin(slot_p, sp_);
         e = panel_factor(sp_, A + k * ld + k, ld, nb, nrows - k, k, info);
         c->span_end(sp, sp_);
@@ -240,7 +242,7 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
             if ((e = trail(r0, r0, k, nb, ncols - r0)) != hipSuccess) return e;
             continue;
         }
-        const int64_t nbn = std::min<int64_t>(c->nb, ncols - r0);
+        const int64_t nbn = std::min<int64_t>(NB, ncols - r0);
         if ((e = trail(r0, r0, k, nb, nbn)) != hipSuccess) return e;           // (a) next block column
         if ((e = c->order(sm, sp_)) != hipSuccess) return e;
         if (r0 + nbn < ncols &&
@@ -325,7 +327,8 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
     hipStream_t sm = c->stream;
     const double* A = c->A.as<double>();
     const int64_t ld = c->ldA, Np = c->Np;
-    const bool la = c->lookahead && c->pstream && Np > c->nb;
+    const int64_t NB = c->block(Np);
+    const bool la = c->lookahead && c->pstream && Np > NB;
     hipStream_t sp_ = la ? c->pstream : sm;
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
     auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
@@ -336,8 +339,8 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
         g.mode = 0; g.lower = 0; g.diag_off = 0;
         return launch_gemm_nt(sm, g);
     };
-    for (int64_t k = 0; k < Np; k += c->nb) {
-        const int64_t nb = std::min<int64_t>(c->nb, Np - k);
+    for (int64_t k = 0; k < Np; k += NB) {
+        const int64_t nb = std::min<int64_t>(NB, Np - k);
         if ((e = trsm_block(sp_, A + k * ld + k, ld, V + k, ldv, m, nb)) != hipSuccess) return e;
         if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
         const int64_t r0 = k + nb;
@@ -346,7 +349,7 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
             if ((e = update(r0, k, nb, Np - r0)) != hipSuccess) return e;
             continue;
         }
-        const int64_t nbn = std::min<int64_t>(c->nb, Np - r0);
+        const int64_t nbn = std::min<int64_t>(NB, Np - r0);
         if ((e = update(r0, k, nb, nbn)) != hipSuccess) return e;
         if ((e = c->order(sm, sp_)) != hipSuccess) return e;
         if (r0 + nbn < Np && (e = update(r0 + nbn, k, nb, Np - r0 - nbn)) != hipSuccess) return e;
@@ -410,7 +413,7 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
 int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail_arg("gpmi_set_option: null argument");
     if (!strcmp(name, "nb")) {
-        if (value < 128 || value % 128) return fail_arg("nb must be a positive multiple of 128");
+        if (value != 0 && (value < 128 || value % 128)) return fail_arg("nb must be 0 (auto) or a positive multiple of 128");
         c->nb = value;
     } else if (!strcmp(name, "ld_pad")) {
         if (value < 0 || value % 2) return fail_arg("ld_pad must be even and >= 0");

@@ -248,7 +248,7 @@ def test_blocking_does_not_change_results(ctx, nb):
         lml = ctx.fit(g["X"], g["y"], 1.0, 2.0, 5e-4)
         mu, sd = ctx.predict(g["Xs"])
     finally:
-        ctx.set_option("nb", 512)
+        ctx.set_option("nb", 0)
     assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
     assert np.allclose(mu, g["mu"], atol=MU_ATOL) and np.allclose(sd, g["sd"], atol=SD_ATOL)
 
