@@ -274,9 +274,14 @@ static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
     p.stagger = (p.nchunks >= 8 && (int64_t)p.Tm * p.Tn >= 1024) ? g_gemm_stagger : 0;
 }
 
+int g_gemm_use_dma = 1;
+
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipSuccess;
     if (a.M % 128 || a.N % 64 || a.K % BK) return hipErrorInvalidValue;
+    // ablation bits >= 256 select the DMA kernel's ablations (low byte passed on)
+    if (g_gemm_use_dma && (!g_gemm_dbg || g_gemm_dbg >= 256) && gemm_dma_eligible(a) && (a.M / 128) * (a.N / 128) >= 256)
+        return launch_gemm_nt_dma(s, a);
     GemmDev p;
     int nblocks;
     if (a.N % 128 == 0) {

@@ -423,6 +423,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_dma")) {
+        g_gemm_use_dma = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_stagger_rule")) {
         g_gemm_stagger_rule = (int)value;
     } else if (!strcmp(name, "gemm_stagger")) {

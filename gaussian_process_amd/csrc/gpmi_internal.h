@@ -29,6 +29,10 @@ struct GemmArgs {
     int row_block_tiles = 1;
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
+// gemm_dma.hip: one-workgroup-per-CU LDS-DMA variant (mode 0, N % 128 == 0)
+bool gemm_dma_eligible(const GemmArgs& a);
+hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
+extern int g_gemm_use_dma;   // 0: never, 1: for launches with >= 256 tiles
 extern int g_gemm_dbg;       // timing-only ablation bits for gpmi_probe_gemm (0 in production)
 extern int g_gemm_stagger_rule;
 extern int g_gemm_stagger;   // tuning switch (GPMI_GEMM_STAGGER / option "gemm_stagger")
