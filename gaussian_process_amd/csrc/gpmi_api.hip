@@ -794,27 +794,34 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
     return rc;
 }
 
-int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
-    if (!c || !gbps || bytes < 4096) return fail_arg("gpmi_probe_hbm_write: bad argument");
+int gpmi_probe_hbm_ex(gpmi_ctx* c, int64_t bytes, int mode, int blocks, double* gbps) {
+    if (!c || !gbps || bytes < 4096 || blocks < 1 || mode < 0 || mode > 5) return fail_arg("gpmi_probe_hbm_ex: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->red.ensure(16 * 8));
     hipStream_t s = c->stream;
     DevBuf buf;
     HIP_TRY(buf.ensure((size_t)bytes));
-    hipError_t e = launch_probe_write(s, buf.as<double>(), bytes / 8);
+    hipError_t e = launch_probe_write(s, buf.as<double>(), bytes / 8, mode == 4 ? 0 : mode, blocks, c->red.as<double>());
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
     (void)hipEventRecord(a, s);
-    if (e == hipSuccess) e = launch_probe_write(s, buf.as<double>(), bytes / 8);
+    const int reps = 3;
+    for (int r = 0; r < reps && e == hipSuccess; ++r)
+        e = launch_probe_write(s, buf.as<double>(), bytes / 8, mode, blocks, c->red.as<double>());
     (void)hipEventRecord(b, s);
     hipError_t e2 = hipEventSynchronize(b);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, a, b);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     buf.release();
-    if (e != hipSuccess) return fail_runtime(e, "probe write");
-    if (e2 != hipSuccess) return fail_runtime(e2, "probe write sync");
-    *gbps = (double)bytes / (ms * 1e-3) / 1e9;
+    if (e != hipSuccess) return fail_runtime(e, "probe kernel");
+    if (e2 != hipSuccess) return fail_runtime(e2, "probe sync");
+    *gbps = (double)bytes * reps / (ms * 1e-3) / 1e9;
     return GPMI_OK;
+}
+
+int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
+    return gpmi_probe_hbm_ex(c, bytes, 0, 2048, gbps);
 }
 
 // ---- device-pointer block primitives (multi-GPU driver) -------------------------

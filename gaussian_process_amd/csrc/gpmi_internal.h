@@ -87,6 +87,6 @@ hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0
 // ---- probes ----------------------------------------------------------------
 hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks, int nacc,
                              unsigned long long* clk);
-hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles);
+hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles, int mode, int blocks, double* sink);
 
 }  // namespace gpmi

@@ -28,8 +28,8 @@ constexpr int RT = 128;        // tile edge
 constexpr int LDS_MAXD = 32;   // largest d staged in LDS; above: rbf_naive_kernel
 
 struct RbfDev {
-    const double* A;
-    const double* B;
+    const double* __restrict__ A;
+    const double* __restrict__ B;
     int64_t nA, nB;
     int d;
     int64_t row0;
@@ -37,7 +37,7 @@ struct RbfDev {
     double coef, sig2, diag_add;
     int symmetric;
     int tri;               // triangular tile enumeration (symmetric, row0 == 0)
-    double* out;
+    double* __restrict__ out;
     int64_t ld;
 };
 
@@ -62,6 +62,51 @@ __device__ __forceinline__ double sq_pw_small(FA a, FB b, int n) {
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
     for (; i < n; ++i) { const double e = a(i) - b(i); res = res + e * e; }
     return res;
+}
+
+// exp(x) for the kernel's arguments (x <= 0): Cody-Waite reduction x = n*ln2 + r with the
+// round-to-nearest n taken from the low bits of x*log2(e) + 1.5*2^52, a degree-13 Taylor
+// polynomial in r (|r| <= ln2/2: truncation 4e-18), and 2^n applied by adding n to the
+// exponent field -- full-rate fp64 FMAs and two integer ops, no v_rndne/v_cvt/v_ldexp.
+// Valid while the result is a normal number; the caller falls back to the library exp
+// for the whole wave if any lane is outside [-700, 0] (or NaN).  Error < 1 ulp (checked
+// against NumPy at the 3-ulp parity tolerance of the K tests).
+__device__ __forceinline__ double exp_neg_fast(double x) {
+    const double MAGIC = 6755399441055744.0;                    // 1.5 * 2^52
+    const double t = fma(x, 1.4426950408889634074, MAGIC);
+    const double n = t - MAGIC;
+    double r = fma(-n, 6.93147180369123816490e-01, x);          // ln2_hi (low bits zero: exact)
+    r = fma(-n, 1.90821492927058770002e-10, r);                 // ln2_lo
+    double q = 1.6059043836821613e-10;                          // 1/13!
+    q = fma(q, r, 2.08767569878681e-09);                        // 1/12!
+    q = fma(q, r, 2.505210838544172e-08);                       // 1/11!
+    q = fma(q, r, 2.755731922398589e-07);                       // 1/10!
+    q = fma(q, r, 2.7557319223985893e-06);                      // 1/9!
+    q = fma(q, r, 2.48015873015873e-05);                        // 1/8!
+    q = fma(q, r, 0.0001984126984126984);                       // 1/7!
+    q = fma(q, r, 0.001388888888888889);                        // 1/6!
+    q = fma(q, r, 0.008333333333333333);                        // 1/5!
+    q = fma(q, r, 0.041666666666666664);                        // 1/4!
+    q = fma(q, r, 0.16666666666666666);                         // 1/3!
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    const int ni = __double2loint(t);                           // n in the low word of t (two's complement)
+    return __hiloint2double(__double2hiint(q) + (ni << 20), __double2loint(q));
+}
+
+// exp for a whole wavefront: fast path unless some lane leaves its domain
+__device__ __forceinline__ void exp_pair(double x0, double x1, double& e0, double& e1) {
+    // x = coef * (sum of squares) with coef < 0 is never positive; one compare on the
+    // smaller argument also catches NaN (the comparison is false)
+    const bool ok = fmin(x0, x1) >= -700.0 && fmax(x0, x1) <= 0.0;
+    if (__all(ok)) {
+        e0 = exp_neg_fast(x0);
+        e1 = exp_neg_fast(x1);
+    } else {
+        e0 = exp(x0);
+        e1 = exp(x1);
+    }
 }
 
 template <int D, class FA, class FB>
@@ -112,8 +157,10 @@ __device__ __forceinline__ bool rbf_map_tile(const RbfDev& p, int& ti, int& tj) 
 
 __device__ __forceinline__ void rbf_finish(const RbfDev& p, int64_t gr, int64_t gc, double s0, double s1,
                                            double* dst) {
-    double v0 = p.sig2 * exp(p.coef * s0);
-    double v1 = p.sig2 * exp(p.coef * s1);
+    double e0, e1;
+    exp_pair(p.coef * s0, p.coef * s1, e0, e1);
+    double v0 = p.sig2 * e0;
+    double v1 = p.sig2 * e1;
     if (p.symmetric) {
         if (gr == gc) v0 = v0 + p.diag_add;
         if (gr == gc + 1) v1 = v1 + p.diag_add;
@@ -179,6 +226,71 @@ __global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
     }
 }
 
+// Fast path for compile-time d (1..8, 16): no LDS, no barrier.  The two b columns of a
+// thread are 2*D contiguous doubles of X (coalesced 16-byte loads), the a row of a wave
+// is wave-uniform and comes through the scalar cache (s_load -> SGPR operands of the
+// VALU).  Interior tiles (all rows and columns inside the matrix, not on the diagonal)
+// skip every padding / diagonal test.
+template <int D, bool EDGE>
+__device__ __forceinline__ void rbf_tile_regs(const RbfDev& p, const double* __restrict__ Ap,
+                                              const double* __restrict__ Bp, double* __restrict__ outp,
+                                              int64_t grow0, int64_t gcol0, int ti) {
+    const int cp = threadIdx.x & 63;
+    const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t gc = gcol0 + 2 * cp;
+    double b0[D], b1[D];
+    if (!EDGE || gc + 1 < p.nB) {
+        const double* bp = Bp + gc * D;
+        if constexpr ((2 * D) % 2 == 0) {
+            d2 t[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) t[k] = *reinterpret_cast<const d2*>(bp + 2 * k);
+#pragma unroll
+            for (int k = 0; k < 2 * D; ++k) {
+                const double v = (k & 1) ? t[k >> 1].y : t[k >> 1].x;
+                if (k < D) b0[k] = v; else b1[k - D] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            b0[k] = (gc < p.nB) ? Bp[gc * D + k] : 0.0;
+            b1[k] = 0.0;
+        }
+    }
+    double* out0 = outp + ((int64_t)ti * RT + 32 * rg) * p.ld + gc;
+#pragma unroll 2
+    for (int r = 0; r < 32; ++r) {
+        const int64_t gr = grow0 + 32 * rg + r;                 // wave-uniform
+        const double* ar = Ap + ((!EDGE || gr < p.nA) ? gr : 0) * D;
+        double av[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) av[k] = ar[k];               // scalar loads (uniform address)
+        const double s0 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b0[k]; });
+        const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
+        if constexpr (EDGE) {
+            rbf_finish(p, gr, gc, s0, s1, out0 + (int64_t)r * p.ld);
+        } else {
+            double e0, e1;
+            exp_pair(p.coef * s0, p.coef * s1, e0, e1);
+            *reinterpret_cast<d2*>(out0 + (int64_t)r * p.ld) = d2{p.sig2 * e0, p.sig2 * e1};
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void rbf_regs_kernel(const double* __restrict__ Ap, const double* __restrict__ Bp,
+                                                        double* __restrict__ outp, const RbfDev p) {
+    int ti, tj;
+    if (!rbf_map_tile(p, ti, tj)) return;
+    const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+    const int64_t gcol0 = (int64_t)tj * RT;
+    const bool inside = grow0 + RT <= p.nA && gcol0 + RT <= p.nB;
+    const bool on_diag = p.symmetric && gcol0 + RT > grow0;      // touches global row == col
+    if (inside && !on_diag) rbf_tile_regs<D, false>(p, Ap, Bp, outp, grow0, gcol0, ti);
+    else rbf_tile_regs<D, true>(p, Ap, Bp, outp, grow0, gcol0, ti);
+}
+
 // any d: operands straight from global memory (L2-resident), one column pair per thread
 __global__ __launch_bounds__(256) void rbf_naive_kernel(const RbfDev p) {
     int ti, tj;
@@ -211,7 +323,7 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     const int64_t nblk = p.tri ? (int64_t)p.Tm * (p.Tm + 1) / 2 : (int64_t)p.Tm * p.Tn;
     dim3 grid((unsigned)nblk), block(256);
     const size_t lds = (size_t)2 * RT * a.d * sizeof(double);
-#define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_kernel<DD>, grid, block, lds, s, p); break
+#define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_regs_kernel<DD>, grid, block, 0, s, p.A, p.B, p.out, p); break
     if (a.d > LDS_MAXD) {
         hipLaunchKernelGGL(rbf_naive_kernel, grid, block, 0, s, p);
     } else {

@@ -229,14 +229,61 @@ hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks,
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(256) void probe_write_kernel(double* buf, int64_t n2) {
+// mode 0: grid-stride 16-byte stores; 1: the same, non-temporal; 2: each block streams one
+// contiguous span, 16-byte stores; 3: span + non-temporal; 4: read-only (16-byte loads)
+template <int MODE>
+__global__ __launch_bounds__(256) void probe_write_kernel(double* buf, int64_t n2, double* sink) {
     d2* p = reinterpret_cast<d2*>(buf);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256)
-        p[i] = d2{1.0, 2.0};
+    const d2 val = d2{1.0, 2.0};
+    if (MODE == 0 || MODE == 1) {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+            if (MODE == 1) __builtin_nontemporal_store(val, p + i);
+            else p[i] = val;
+        }
+    } else if (MODE == 2 || MODE == 3) {
+        const int64_t span = (n2 + gridDim.x - 1) / gridDim.x;
+        const int64_t i0 = (int64_t)blockIdx.x * span, i1 = (i0 + span < n2) ? i0 + span : n2;
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            if (MODE == 3) __builtin_nontemporal_store(val, p + i);
+            else p[i] = val;
+        }
+    } else if (MODE == 5) {
+        // the K-build store pattern without its arithmetic: 128 x 128 tiles of a square
+        // matrix (ld = side + 544), a wave stores 1-KiB row segments, 32 rows per thread
+        int64_t side = (int64_t)sqrt((double)(2 * n2));
+        side = side / 128 * 128;
+        const int64_t ld = side + 544;
+        const int T = (int)(side / 128);
+        for (int t = blockIdx.x; t < T * T; t += gridDim.x) {
+            const int ti = t / T, tj = t - ti * T;
+            const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+            double* dst = buf + ((int64_t)ti * 128 + 32 * rg) * ld + (int64_t)tj * 128 + 2 * cp;
+            if (((int64_t)ti * 128 + 32 * rg + 31) * ld + (int64_t)tj * 128 + 2 * cp + 1 < 2 * n2) {
+#pragma unroll 4
+                for (int r = 0; r < 32; ++r) *reinterpret_cast<d2*>(dst + (int64_t)r * ld) = val;
+            }
+        }
+    } else {
+        double acc = 0.;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n2; i += (int64_t)gridDim.x * 256) {
+            const d2 v = p[i];
+            acc += v.x + v.y;
+        }
+        if (acc == 123.456) sink[0] = acc;
+    }
 }
 
-hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles) {
-    hipLaunchKernelGGL(probe_write_kernel, dim3(2048), dim3(256), 0, s, buf, n_doubles / 2);
+hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles, int mode, int blocks, double* sink) {
+    const int64_t n2 = n_doubles / 2;
+    dim3 g((unsigned)blocks), b(256);
+    switch (mode) {
+        case 1: hipLaunchKernelGGL(probe_write_kernel<1>, g, b, 0, s, buf, n2, sink); break;
+        case 2: hipLaunchKernelGGL(probe_write_kernel<2>, g, b, 0, s, buf, n2, sink); break;
+        case 3: hipLaunchKernelGGL(probe_write_kernel<3>, g, b, 0, s, buf, n2, sink); break;
+        case 4: hipLaunchKernelGGL(probe_write_kernel<4>, g, b, 0, s, buf, n2, sink); break;
+        case 5: hipLaunchKernelGGL(probe_write_kernel<5>, g, b, 0, s, buf, n2, sink); break;
+        default: hipLaunchKernelGGL(probe_write_kernel<0>, g, b, 0, s, buf, n2, sink); break;
+    }
     return hipGetLastError();
 }
 

@@ -75,6 +75,11 @@ class GPContext:
         check(self._lib.gpmi_probe_hbm_write(self._h, int(nbytes), C.byref(v)))
         return v.value
 
+    def probe_hbm_ex(self, nbytes, mode, blocks):
+        v = C.c_double()
+        check(self._lib.gpmi_probe_hbm_ex(self._h, int(nbytes), int(mode), int(blocks), C.byref(v)))
+        return v.value
+
     # ---- a1: RBF_kernel -------------------------------------------------------------
     def rbf(self, a, b, sigma, l):
         a = as_f64(a, 2, "a")

@@ -143,6 +143,9 @@ int gpmi_probe_gemm(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, i
                     double* out);
 /* streaming-store bandwidth (GB/s) over `bytes` of device memory */
 int gpmi_probe_hbm_write(gpmi_ctx* ctx, int64_t bytes, double* gbps);
+/* streaming bandwidth with a chosen access form: mode 0 grid-stride 16-byte stores, 1 the same
+ * non-temporal, 2 one contiguous span per workgroup, 3 span + non-temporal, 4 16-byte loads */
+int gpmi_probe_hbm_ex(gpmi_ctx* ctx, int64_t bytes, int mode, int blocks, double* gbps);
 
 /* ---------------------------------------------------------------------------
  * Device-pointer block primitives for the multi-GPU (row-block cyclic) driver
