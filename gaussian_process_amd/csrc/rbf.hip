@@ -97,9 +97,8 @@ __device__ __forceinline__ double exp_neg_fast(double x) {
 
 // exp for a whole wavefront: fast path unless some lane leaves its domain
 __device__ __forceinline__ void exp_pair(double x0, double x1, double& e0, double& e1) {
-    // x = coef * (sum of squares) with coef < 0 is never positive; one compare on the
-    // smaller argument also catches NaN (the comparison is false)
-    const bool ok = fmin(x0, x1) >= -700.0 && fmax(x0, x1) <= 0.0;
+    // x = coef * (sum of squares) with coef < 0 is never positive; NaN fails the compare
+    const bool ok = (x0 >= -700.0) & (x1 >= -700.0);
     if (__all(ok)) {
         e0 = exp_neg_fast(x0);
         e1 = exp_neg_fast(x1);
