@@ -91,7 +91,8 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         from gaussian_process_amd.dist import DistGP
-        gp = DistGP(local_rank)
+        gp = DistGP(local_rank, nb=int(os.environ.get("GPMI_DIST_NB", "512")),
+                    lookahead=os.environ.get("GPMI_DIST_LOOKAHEAD", "1") == "1")
         gp.set_train(X, y)
         gp.set_test(Xs)
 
@@ -154,8 +155,10 @@ def main():
                        "partition": "single GPU" if world == 1 else "row-block cyclic x%d" % world},
             "lml": float(lml),
         }
-        if stage:
-            k = args.steps if world == 1 else 1
+        if world > 1 and stage:
+            out["stages_ms"] = stage            # last step, rank 0: fit / predict wall
+        if world == 1 and stage:
+            k = args.steps
             trail_ms = stage.get("chol_trail", 0.0) / k
             trail_flops = stage.get("trail_flops", 0.0) / k
             launches = stage.get("trail_launches", 0.0) / k

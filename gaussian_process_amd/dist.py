@@ -108,7 +108,7 @@ class HipBlockOps:
 class DistGP:
     """Row-block cyclic GP fit / predict over the ranks of `group` (default: WORLD)."""
 
-    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None):
+    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=True):
         if not dist.is_initialized():
             raise RuntimeError("DistGP needs torch.distributed (init_process_group) -- one rank per GPU")
         if nb <= 0 or nb % 128:
@@ -120,6 +120,7 @@ class DistGP:
         self.dev = self.ops.device
         self.NB = int(nb)
         self.ld_pad = int(ld_pad) // 2 * 2
+        self.lookahead = bool(lookahead)
         self.have_factor = False
         self.have_test = False
         self.stage_ms = {}
@@ -166,7 +167,8 @@ class DistGP:
         cmax = max(self._nblocks(r) for r in range(G))
         self.send = self._tensor(max(cmax, 1) * NB, NB)
         self.recv = self._tensor(G * max(cmax, 1) * NB, NB)
-        self.Pfull = self._tensor(max(self.T - 1, 1) * NB, NB)
+        self.Pbuf = [self._tensor(max(self.T - 1, 1) * NB, NB) for _ in range(2 if self.lookahead else 1)] \
+            if G > 1 else [None, None]
         self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         self.red = self._tensor(max(self.nloc, 1) + 1, 2)
         self.m = self._tensor(self.Np)
@@ -186,14 +188,109 @@ class DistGP:
         self.rowmap = torch.tensor(flat, dtype=torch.int32, device=self.dev)
         self.rowmap_off = offs
         self.rowmap_len = [len(t) for t in tabs]
+        # lookahead part (b) of step k: my rows of blocks > k+1 update columns from block k+2 on
+        tabs, offs = [], []
+        for k in range(self.T - 2):
+            ls = self._lstart(k + 1)
+            offs.append(sum(len(t) for t in tabs))
+            t = []
+            for li in range(ls, self.nloc):
+                t += [(self.my_blocks[li] - k - 1) * NB] * bands
+            if self.rank == self.ry:
+                t += [self.Np - (k + 2) * NB] * (YB // 128)
+            tabs.append(t)
+        flat = [v for t in tabs for v in t] or [0]
+        self.rowmapB = torch.tensor(flat, dtype=torch.int32, device=self.dev)
+        self.rowmapB_off = offs
+        self.rowmapB_len = [len(t) for t in tabs]
         self.have_factor = False
         self.have_test = False
 
+    # ------------------------------------------------------------------ streams (no-ops on CPU)
+    def _cuda(self):
+        return self.dev.type == "cuda"
+
+    def _side(self):
+        """context manager: run on the side (panel + collectives) stream"""
+        import contextlib
+        if not self._cuda():
+            return contextlib.nullcontext()
+        if getattr(self, "_side_stream", None) is None:
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            self._side_stream = torch.cuda.Stream(device=self.dev, priority=hi)
+        return torch.cuda.stream(self._side_stream)
+
+    def _order(self, first_is_side):
+        """make the other stream wait for everything queued so far on the first one"""
+        if not self._cuda():
+            return
+        main = torch.cuda.current_stream(self.dev)
+        with self._side():
+            side = torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        if first_is_side:
+            ev.record(side)
+            main.wait_event(ev)
+        else:
+            ev.record(main)
+            side.wait_event(ev)
+
     # ------------------------------------------------------------------ fit
+    def _panel_step(self, k, P):
+        """Block column k: owner factors the diagonal block, broadcast, every rank solves its
+        rows below, all-gather of the panel column into P (natural block order)."""
+        ops, NB, G, A = self.ops, self.NB, self.G, self.A
+        owner = k % G
+        c0 = k * NB
+        if self.rank == owner:
+            li = k // G
+            diag = A[li * NB:(li + 1) * NB, c0:c0 + NB]
+            ops.potrf_block(diag, c0, self.info)
+            self.Lkk.copy_(diag)
+        if G > 1:
+            dist.broadcast(self.Lkk, src=self._src(owner), group=self.group)
+        ls = self._lstart(k)
+        r0 = ls * NB
+        m = self.rows - r0
+        if m > 0:
+            ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
+        if k == self.T - 1 or G == 1:
+            return
+        cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
+        cmax = max(cnts)
+        cnt = cnts[self.rank]
+        nbelow = self.T - k - 1
+        send = self.send[:cmax * NB]
+        if cnt:
+            send[:cnt * NB].copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
+        recv = self.recv[:G * cmax * NB]
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        Pv = P[:nbelow * NB].view(nbelow, NB, NB)
+        R = recv.view(G, cmax, NB, NB)
+        for r in range(G):
+            if cnts[r]:
+                first = r + self._lstart(k, r) * G        # global index of r's first block below k
+                Pv[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
+
+    def _panel_view(self, k, P):
+        """the panel column below block k in natural order (blocks k+1 ..)"""
+        nbelow = self.T - k - 1
+        if self.G == 1:
+            r0 = self._lstart(k) * self.NB
+            return self.A[r0:r0 + nbelow * self.NB, k * self.NB:(k + 1) * self.NB]
+        return P[:nbelow * self.NB]
+
     def factorize(self, sigma, ell, noise_var):
         """K + sI -> L (distributed), m = L^-1 y; returns the log-marginal-likelihood
         (tune_hyperparms_regression.py:312) on every rank.  Raises LinAlgError on every
-        rank if a pivot is not positive."""
+        rank if a pivot is not positive.
+
+        With lookahead (default) the trailing update of step k is split: (a) block column
+        k+1 first, then the side stream runs the whole panel step k+1 (diagonal block,
+        broadcast, solves, all-gather) while (b) the remaining columns update on the main
+        stream -- collectives and the latency-bound panel kernels hide behind the MFMA work."""
+        import time
+        t_begin = time.perf_counter()
         ops, NB, G, A = self.ops, self.NB, self.G, self.A
         self.sigma, self.ell = float(sigma), float(ell)
         self.have_factor = False
@@ -205,47 +302,41 @@ class DistGP:
         if self.yrow is not None:
             A[self.yrow:self.yrow + YB, :self.Np].zero_()
             A[self.yrow, :self.N].copy_(self.y)
-        for k in range(self.T):
-            owner = k % G
-            c0 = k * NB
-            if self.rank == owner:
-                li = k // G
-                diag = A[li * NB:(li + 1) * NB, c0:c0 + NB]
-                ops.potrf_block(diag, c0, self.info)
-                self.Lkk.copy_(diag)
-            if G > 1:
-                dist.broadcast(self.Lkk, src=self._src(owner), group=self.group)
-            ls = self._lstart(k)
-            r0 = ls * NB
-            m = self.rows - r0
-            if m > 0:
-                ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
-            if k == self.T - 1:
-                break
-            # panel column below block k, natural block order, on every rank
-            cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
-            cmax = max(cnts)
-            cnt = cnts[self.rank]
-            nbelow = self.T - k - 1
-            if G > 1:
-                send = self.send[:cmax * NB]
-                if cnt:
-                    send[:cnt * NB].copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
-                recv = self.recv[:G * cmax * NB]
-                dist.all_gather_into_tensor(recv, send, group=self.group)
-                P = self.Pfull[:nbelow * NB].view(nbelow, NB, NB)
-                R = recv.view(G, cmax, NB, NB)
-                for r in range(G):
-                    if cnts[r]:
-                        first = r + self._lstart(k, r) * G        # global index of r's first block below k
-                        P[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
-                Pfull = self.Pfull[:nbelow * NB]
-            else:
-                Pfull = A[r0:r0 + nbelow * NB, c0:c0 + NB]
-            if m > 0:
-                off, ln = self.rowmap_off[k], self.rowmap_len[k]
-                ops.gemm_nt_rowmap(A[r0:r0 + m, c0 + NB:self.Np], A[r0:r0 + m, c0:c0 + NB], Pfull,
-                                   self.rowmap[off:off + ln], 128)
+        T = self.T
+        if not self.lookahead:
+            for k in range(T):
+                self._panel_step(k, self.Pbuf[0])
+                if k == T - 1:
+                    break
+                r0 = self._lstart(k) * NB
+                m = self.rows - r0
+                if m > 0:
+                    off, ln = self.rowmap_off[k], self.rowmap_len[k]
+                    ops.gemm_nt_rowmap(A[r0:r0 + m, (k + 1) * NB:self.Np], A[r0:r0 + m, k * NB:(k + 1) * NB],
+                                       self._panel_view(k, self.Pbuf[0]), self.rowmap[off:off + ln], 128)
+        else:
+            self._order(first_is_side=False)              # side waits for the K build
+            with self._side():
+                self._panel_step(0, self.Pbuf[0])
+            for k in range(T - 1):
+                self._order(first_is_side=True)           # main waits for panel k
+                P = self._panel_view(k, self.Pbuf[k % 2])
+                c0, c1 = k * NB, (k + 1) * NB
+                r0 = self._lstart(k) * NB                 # my rows of blocks > k (and the y rows)
+                m = self.rows - r0
+                if m > 0:                                 # (a) block column k+1
+                    ops.gemm_nt(A[r0:r0 + m, c1:c1 + NB], A[r0:r0 + m, c0:c0 + NB], P[:NB])
+                self._order(first_is_side=False)          # side waits for (a)
+                with self._side():
+                    self._panel_step(k + 1, self.Pbuf[(k + 1) % 2])
+                if k + 2 < T:                             # (b) the remaining columns
+                    r1 = self._lstart(k + 1) * NB         # my rows of blocks > k+1 (and the y rows)
+                    m1 = self.rows - r1
+                    if m1 > 0:
+                        off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
+                        ops.gemm_nt_rowmap(A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], P[NB:],
+                                           self.rowmapB[off:off + ln], 128)
+            self._order(first_is_side=True)               # main waits for the last panel
         # not-PD: smallest failing global column over all ranks
         if G > 1:
             dist.all_reduce(self.info, op=dist.ReduceOp.MIN, group=self.group)
@@ -274,6 +365,7 @@ class DistGP:
             logsum += float(allp[r, 0])
         mtm = float(allp[self.ry, 1])
         self.have_factor = True
+        self.stage_ms["fit"] = (time.perf_counter() - t_begin) * 1e3
         return -.5 * mtm - logsum - self.N / 2.0 * math.log(2 * math.pi)
 
     # ------------------------------------------------------------------ predict
@@ -288,7 +380,7 @@ class DistGP:
             dist.broadcast(self.Xs, src=self._src(0), group=self.group)
         self.ldv = max(self.nloc, 1) * self.NB + self.ld_pad
         self.V = self._tensor(self.n_p, self.ldv)
-        self.Xk = self._tensor(self.n_p, self.NB)
+        self.Xk = [self._tensor(self.n_p, self.NB) for _ in range(2)]
         self.dots = self._tensor(2, self.n_p)
         self.m_loc = self._tensor(max(self.nloc, 1) * self.NB)
         self.have_test = True
@@ -299,31 +391,58 @@ class DistGP:
             raise ValueError("no factorisation resident (call factorize)")
         if not self.have_test:
             raise ValueError("no test set (call set_test)")
+        import time
+        t_begin = time.perf_counter()
         ops, NB, G, A, V = self.ops, self.NB, self.G, self.A, self.V
         for li, b in enumerate(self.my_blocks):
             ops.rbf_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, self.d, self.n_p, NB,
                           self.sigma, self.ell, V[:, li * NB:(li + 1) * NB])
             self.m_loc[li * NB:(li + 1) * NB].copy_(self.m[b * NB:(b + 1) * NB])
-        for k in range(self.T):
-            owner = k % G
-            c0 = k * NB
-            if self.rank == owner:
+        T = self.T
+
+        def solve_block(k, Xk):
+            """owner: v^T block k <- block * L_kk^-T; everyone receives it in Xk"""
+            if self.rank == k % G:
                 li = k // G
                 blk = V[:, li * NB:(li + 1) * NB]
-                ops.trsm_block(A[li * NB:(li + 1) * NB, c0:c0 + NB], blk)
+                ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
                 if G > 1:
-                    self.Xk.copy_(blk)
-            if k == self.T - 1:
-                break
-            if G > 1:
-                dist.broadcast(self.Xk, src=self._src(owner), group=self.group)
-                Xk = self.Xk
-            else:
-                Xk = V[:, k * NB:(k + 1) * NB]
-            ls = self._lstart(k)
-            cnt = self.nloc - ls
-            if cnt > 0:
-                ops.gemm_nt(V[:, ls * NB:self.nloc * NB], Xk, A[ls * NB:self.nloc * NB, c0:c0 + NB])
+                    Xk.copy_(blk)
+            if G > 1 and k < T - 1:
+                dist.broadcast(Xk, src=self._src(k % G), group=self.group)
+
+        def xk_view(k):
+            return self.Xk[k % 2] if G > 1 else V[:, k * NB:(k + 1) * NB]
+
+        if not self.lookahead:
+            for k in range(T):
+                solve_block(k, self.Xk[0])
+                if k == T - 1:
+                    break
+                ls = self._lstart(k)
+                if self.nloc - ls > 0:
+                    ops.gemm_nt(V[:, ls * NB:self.nloc * NB], self.Xk[0] if G > 1 else xk_view(k),
+                                A[ls * NB:self.nloc * NB, k * NB:(k + 1) * NB])
+        else:
+            self._order(first_is_side=False)
+            with self._side():
+                solve_block(0, self.Xk[0])
+            for k in range(T - 1):
+                self._order(first_is_side=True)            # main waits for solved block k
+                Xk = xk_view(k)
+                c0 = k * NB
+                ls = self._lstart(k)
+                own_next = (self.rank == (k + 1) % G)
+                if own_next:                               # (a) my block k+1 first
+                    li = (k + 1) // G
+                    ops.gemm_nt(V[:, li * NB:(li + 1) * NB], Xk, A[li * NB:(li + 1) * NB, c0:c0 + NB])
+                self._order(first_is_side=False)
+                with self._side():
+                    solve_block(k + 1, self.Xk[(k + 1) % 2])
+                lb = self._lstart(k + 1)                   # (b) my blocks beyond k+1
+                if self.nloc - lb > 0:
+                    ops.gemm_nt(V[:, lb * NB:self.nloc * NB], Xk, A[lb * NB:self.nloc * NB, c0:c0 + NB])
+            self._order(first_is_side=True)
         self.dots.zero_()
         if self.nloc:
             ops.row_dots(V, self.nloc * NB, self.m_loc, self.dots[0], self.dots[1])
@@ -339,6 +458,7 @@ class DistGP:
             mu += alld[r, 0]
             sq += alld[r, 1]
         var = self.sigma ** 2 - sq[:self.n]
+        self.stage_ms["predict"] = (time.perf_counter() - t_begin) * 1e3
         with np.errstate(invalid="ignore"):
             out2 = np.sqrt(var) if want_sd else var
         return mu[:self.n].copy(), out2

@@ -18,10 +18,10 @@ def _free_port():
         return str(s.getsockname()[1])
 
 
-def _run(world, backend, device, tmp_path, N, d, n, nb):
+def _run(world, backend, device, tmp_path, N, d, n, nb, lookahead=1):
     port = _free_port()
     out = str(tmp_path / "res")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", DISTGP_LOOKAHEAD=str(lookahead))
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), str(r), str(world),
                                port, backend, device, out, str(N), str(d), str(n), str(nb)], env=env)
              for r in range(world)]
@@ -66,8 +66,15 @@ def test_three_ranks_gloo_cpu_uneven_blocks(oracle, tmp_path):
     _check(res, oracle, 520, 2, 33)
 
 
+def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
+    res = _run(2, "gloo", "cpu", tmp_path, 640, 4, 40, 128, lookahead=0)
+    _check(res, oracle, 640, 4, 40)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,N,d,n,nb", [(2, 1500, 8, 200, 256), (3, 2100, 8, 130, 128), (2, 4096, 8, 512, 512)])
-def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb):
-    res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb)
+@pytest.mark.parametrize("world,N,d,n,nb,la", [(2, 1500, 8, 200, 256, 1), (3, 2100, 8, 130, 128, 1),
+                                                (2, 4096, 8, 512, 512, 1), (2, 1500, 8, 200, 256, 0),
+                                                (1, 1300, 8, 100, 256, 1)])
+def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
+    res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb, lookahead=la)
     _check(res, oracle, N, d, n)
