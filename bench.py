@@ -86,10 +86,17 @@ def main():
     y = np.sin(0.9 * X.sum(1)) + np.sqrt(5e-4) * rng.standard_normal(N)
     Xs = rng.uniform(-1, 1, (n, d))
 
+    # rehearsal on a one-GPU box (tests only): GPMI_BENCH_BACKEND=gloo GPMI_BENCH_ONE_DEVICE=1
+    if os.environ.get("GPMI_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("GPMI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
         from gaussian_process_amd.dist import DistGP
         gp = DistGP(local_rank, nb=int(os.environ.get("GPMI_DIST_NB", "512")),
                     lookahead=os.environ.get("GPMI_DIST_LOOKAHEAD", "1") == "1")

@@ -473,3 +473,46 @@ class DistGP:
 
     def timers(self):
         return dict(self.stage_ms)
+
+
+def sharded_lml_batch(triples, evaluate, group=None):
+    """Batched log-marginal-likelihood over hyper-parameter triples (BASELINE config 5;
+    the reference's loops at tune_hyperparms_regression.py:368-369, 385-386), sharded over
+    the ranks: triple t is evaluated by rank t % G with the single-GPU path -- the
+    factorisations are independent, so there is no data-path collective, only one
+    all-gather of the T results.
+
+    triples: (T, 3) rows of (l, sigma_f, noise_var), identical on every rank.
+    evaluate: callable(sub_triples (t, 3)) -> (lml (t,), status (t,)), e.g.
+              GPContext.lml_batch after GPContext.set_train on every rank.
+    Returns (lml (T,), status (T,)) on every rank, NaN where a factorisation failed.
+    """
+    t = np.ascontiguousarray(triples, dtype=np.float64)
+    if t.ndim != 2 or t.shape[1] != 3:
+        raise ValueError("triples must be (T, 3) = (l, sigma_f, noise_var)")
+    T = t.shape[0]
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        lml, st = evaluate(t)
+        return np.asarray(lml, dtype=np.float64), np.asarray(st, dtype=np.int32)
+    G, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (T + G - 1) // G
+    mine = t[rank::G]
+    lml = np.full(per, np.nan)
+    st = np.zeros(per)
+    if len(mine):
+        l, s_ = evaluate(mine)
+        lml[:len(mine)] = l
+        st[:len(mine)] = s_
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    send = torch.from_numpy(np.concatenate([lml, st])).to(dev)
+    recv = torch.empty(G * 2 * per, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    R = recv.cpu().numpy().reshape(G, 2, per)
+    out = np.empty(T)
+    out_s = np.empty(T, dtype=np.int32)
+    for r in range(G):
+        cnt = len(range(r, T, G))
+        out[r::G] = R[r, 0, :cnt]
+        out_s[r::G] = R[r, 1, :cnt].astype(np.int32)
+    return out, out_s

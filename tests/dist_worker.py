@@ -36,7 +36,26 @@ def main():
         gp.factorize(1.0, 2.0, -0.7)
     except np.linalg.LinAlgError as e:
         raised = int(e.bad_pivot)
-    np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised)
+    # config-5 style batch: triples sharded over ranks, no data-path collective
+    from gaussian_process_amd.dist import sharded_lml_batch
+    triples = np.array([[l, sf, s2] for l in (1.0, 2.0) for sf in (0.7, 1.0, 1.4) for s2 in (5e-4,)] + [[2.0, 1.0, -0.7]])
+    if device == "cpu":
+        def evaluate(tr):
+            vals, st = [], []
+            for l, sf, s2 in tr:
+                try:
+                    vals.append(O.compute_mar_likelihood(X, None, y, sf, l, s=s2)); st.append(0)
+                except np.linalg.LinAlgError:
+                    vals.append(np.nan); st.append(1)
+            return np.array(vals), np.array(st)
+    else:
+        from gaussian_process_amd import GPContext
+        ctx = GPContext(0)
+        ctx.set_train(X, y)
+        evaluate = ctx.lml_batch
+    blml, bst = sharded_lml_batch(triples, evaluate)
+    np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised,
+             blml=blml, bst=bst, triples=triples)
     dist.barrier()
     dist.destroy_process_group()
 

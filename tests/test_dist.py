@@ -50,9 +50,16 @@ def _check(res, oracle, N, d, n):
         assert np.max(np.abs(r["mu2"] - ref2["mu"])) <= 1e-9
         assert np.max(np.abs(r["sd2"] - np.sqrt(ref2["var"]))) <= 1e-9
         assert int(r["raised"]) == kbad
+        # sharded batch of log-marginal-likelihoods (config 5): per-triple oracle, NaN + status for the bad one
+        for t, (l, sf, s2) in enumerate(r["triples"]):
+            if s2 < 0:
+                assert np.isnan(r["blml"][t]) and r["bst"][t] == 1
+            else:
+                want = oracle.compute_mar_likelihood(X, None, y, sf, l, s=s2)
+                assert abs(r["blml"][t] - want) <= 1e-10 * abs(want) and r["bst"][t] == 0
     for r in res[1:]:                      # every rank returns the same bits
-        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2"):
-            assert np.array_equal(r[key], res[0][key]), key
+        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml"):
+            assert np.array_equal(r[key], res[0][key], equal_nan=True), key
 
 
 @pytest.mark.parametrize("N,d,n,nb", [(700, 3, 50, 128), (300, 8, 140, 256)])
