@@ -43,6 +43,8 @@ struct GemmDmaDev {
     const int32_t* row_ncols;
     int row_block_tiles;
     int S, logS, SM, SN, tri, nsuper;
+    int stagger;
+    unsigned long long* stamps;   // diagnostic build only (dbg & 16): per-tile phase clocks
     int dbg;   // timing-only ablations (probe instantiation): 1 no DMA in the loop, 2 no barrier/waits, 8 no epilogue
 };
 
@@ -72,10 +74,17 @@ __device__ __forceinline__ bool dma_map_tile(const GemmDmaDev& p, int& ti, int& 
 constexpr int DMA_TM = 128, DMA_TN = 128;
 constexpr int DMA_STAGE_SLOTS = (DMA_TM + DMA_TN) * 8;     // 16-byte slots per stage (A then B)
 constexpr int DMA_STAGES = 3;
-constexpr int DMA_PER_WAVE = 8;                            // DMA wave-instructions per wave per K step
 
-template <bool DBG>
-__global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmDmaDev p) {
+// MI = MFMA row tiles per wave: 4 -> 4 waves of 64 x 64 (256 threads, one wave per SIMD),
+//                               2 -> 8 waves of 32 x 64 (512 threads, two waves per SIMD: the
+//                               matrix pipe is fed at its full 64-cycle cadence, which a single
+//                               wave does not reach on fp64 -- measured ~72 cycles per MFMA)
+template <int MI, bool DBG>
+__global__ __launch_bounds__(1024 / MI, (MI == 4) ? 2 : 3) void gemm_nt_dma_kernel(const GemmDmaDev p) {
+    constexpr int NWAVES = 16 / MI;                 // 4 or 8
+    constexpr int DPW = 32 / NWAVES;                // DMA wave-instructions per wave per K step (8 or 4)
+    constexpr int RPW = DMA_TM / NWAVES;            // operand rows a wave moves per K step (32 or 16)
+    constexpr int NFR = MI + 4;                     // fragment reads per half step
     const int dbg = DBG ? p.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     int ti, tj;
@@ -89,10 +98,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmDmaDev p)
         if ((int64_t)tj * DMA_TN >= p.row_ncols[ti / p.row_block_tiles]) return;
     }
 
+    // All tiles of a launch take the same time, so without help every CU reaches its
+    // C read-modify-write at the same moment (one HBM burst per residency wave, idle
+    // memory in between).  The workgroups of the first residency wave start after
+    // 0..15 sixteenths of a tile time; successors inherit the phase.  Speed only.
+    if (p.stagger && blockIdx.x < 256) {
+        const unsigned phase = (blockIdx.x * 0x9E3779B1u) >> 28;              // 0..15
+        const int naps = (int)(phase * (unsigned)p.nchunks) >> 2;             // x 1024 cycles: nch*4096/16 per phase unit
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+    if (DBG && (dbg & 16)) st0 = clock64();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = (wave >> 1) * 64;
+    const int wr = (wave >> 1) * (16 * MI);
     const int wc = (wave & 1) * 64;
     const int fr = lane & 15;
     const int fg = lane >> 4;
@@ -101,26 +122,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmDmaDev p)
     // 8 rows (= 64 slots = 1 KiB of LDS) per instruction; lane l -> row 8i + (l>>3), k-pair (l&7)^(row&7)
     const int drow = lane >> 3;
     const int dkp = (lane & 7) ^ (drow & 7);
-    const double* a_src = p.A + ((int64_t)ti * DMA_TM + 32 * wave + drow) * p.lda + dkp * 2;
-    const double* b_src = p.B + ((int64_t)tj * DMA_TN + 32 * wave + drow) * p.ldb + dkp * 2;
+    const double* a_src = p.A + ((int64_t)ti * DMA_TM + RPW * wave + drow) * p.lda + dkp * 2;
+    const double* b_src = p.B + ((int64_t)tj * DMA_TN + RPW * wave + drow) * p.ldb + dkp * 2;
     const int64_t a_step = 8 * p.lda, b_step = 8 * p.ldb;
     GPMI_LDS char* lds = (GPMI_LDS char*)smem_raw;
-    const int a_dst = (32 * wave) * 128;                         // byte offset inside a stage
-    const int b_dst = DMA_TM * 128 + (32 * wave) * 128;
+    const int a_dst = (RPW * wave) * 128;                        // byte offset inside a stage
+    const int b_dst = DMA_TM * 128 + (RPW * wave) * 128;
 
-    // piece i (0..3) of the DMA of one K step: one A and one B wave-instruction
-    auto issue_dma_piece = [&](int chunk, int i) {
+    // DMA wave-instruction q (0..DPW/2-1: A rows, DPW/2..DPW-1: B rows) of K step `chunk`
+    auto issue_dma_one = [&](int chunk, int q) {
         const int st = chunk % DMA_STAGES;
         GPMI_LDS char* base = lds + st * (DMA_STAGE_SLOTS * 16);
         const int k0 = chunk * 16;
-        __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(a_src + i * a_step + k0),
-                                         (GPMI_LDS void*)(base + a_dst + i * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(b_src + i * b_step + k0),
-                                         (GPMI_LDS void*)(base + b_dst + i * 1024), 16, 0, 0);
+        if (q < DPW / 2)
+            __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(a_src + q * a_step + k0),
+                                             (GPMI_LDS void*)(base + a_dst + q * 1024), 16, 0, 0);
+        else
+            __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(b_src + (q - DPW / 2) * b_step + k0),
+                                             (GPMI_LDS void*)(base + b_dst + (q - DPW / 2) * 1024), 16, 0, 0);
     };
     auto issue_dma = [&](int chunk) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) issue_dma_piece(chunk, i);
+        for (int q = 0; q < DPW; ++q) issue_dma_one(chunk, q);
     };
 
     // ---- fragment read offsets (16-byte slots): row*8 + (kp ^ (row&7)); rows of a fragment
@@ -129,113 +152,152 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dma_kernel(const GemmDmaDev p)
     const int sl0 = fr * 8 + (fg ^ x7);            // k-pairs 0..3  (half step 0)
     const int sl1 = fr * 8 + ((4 + fg) ^ x7);      // k-pairs 4..7  (half step 1)
     const d2* smem = reinterpret_cast<const d2*>(smem_raw);
-    auto read_frags = [&](int chunk, int half, d2 (&fa)[4], d2 (&fb)[4]) {
+    // fragment read q (0..MI-1: A fragments, MI..MI+3: B fragments)
+    auto read_one = [&](int chunk, int half, int q, d2 (&fa)[MI], d2 (&fb)[4]) {
         const d2* sa = smem + (chunk % DMA_STAGES) * DMA_STAGE_SLOTS;
         const d2* sb = sa + DMA_TM * 8;
         const int sl = half ? sl1 : sl0;
+        if (q < MI) fa[q] = sa[(wr + 16 * q) * 8 + sl];
+        else fb[q - MI] = sb[(wc + 16 * (q - MI)) * 8 + sl];
+    };
+    auto read_frags = [&](int chunk, int half, d2 (&fa)[MI], d2 (&fb)[4]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[i] = sa[(wr + 16 * i) * 8 + sl];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = sb[(wc + 16 * j) * 8 + sl];
+        for (int q = 0; q < NFR; ++q) read_one(chunk, half, q, fa, fb);
     };
 
-    d4 acc[4][4];
+    d4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = d4{0., 0., 0., 0.};
-    auto mma_x_row = [&](const d2 (&fa)[4], const d2 (&fb)[4], int i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-    };
-    auto mma_x = [&](const d2 (&fa)[4], const d2 (&fb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mma_x_row(fa, fb, i);
-    };
-    auto mma_y = [&](const d2 (&fa)[4], const d2 (&fb)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-    };
-
     const int nch = p.nchunks;
-    d2 fa0[4], fb0[4], fa1[4], fb1[4];
+    d2 fa0[MI], fb0[4], fa1[MI], fb1[4];
     // prologue: stages 0 and 1 in flight, stage 0 landed and published, F0 loaded
     issue_dma(0);
     if (nch > 1) {
         issue_dma(1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if constexpr (DPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     read_frags(0, 0, fa0, fb0);
+    if (DBG && (dbg & 16)) st1 = clock64();
 
+#define GPMI_MFMA_X(FA, FB, T) acc[(T) >> 2][(T) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[(T) >> 2].x, FB[(T) & 3].x, acc[(T) >> 2][(T) & 3], 0, 0, 0)
+#define GPMI_MFMA_Y(FA, FB, T) acc[(T) >> 2][(T) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[(T) >> 2].y, FB[(T) & 3].y, acc[(T) >> 2][(T) & 3], 0, 0, 0)
+#define GPMI_FENCE() __builtin_amdgcn_sched_barrier(0)
+    constexpr int NT = 4 * MI;                      // MFMAs per quarter step (16 or 8)
+    constexpr int NSLOT = NT / 2;                   // one side instruction behind every second MFMA
+
+    // Every non-MFMA instruction of the step sits alone behind two MFMAs (128 matrix-pipe
+    // cycles of cover for an LDS-DMA issue of ~60 cycles or a ds_read of ~16):
+    //   quarter 0 (F0 .x): the DMA wave-instructions of step c+2
+    //   quarter 1 (F0 .y): the fragment reads F1 <- stage c, k-pairs 4..7
+    //   wait + barrier (publishes stage c+1, retires the reads of the stage DMA(c+3) overwrites)
+    //   quarter 2 (F1 .x): (rest of the fragment reads when MI = 2)
+    //   quarter 3 (F1 .y): the fragment reads F0 <- stage c+1, k-pairs 0..3
     for (int c = 0; c < nch; ++c) {
-        const bool more2 = (c + 2 < nch);
-        // half step 0: 16 MFMAs (.x of F0) with the DMA of step c+2 issued in their shadow,
-        // two wave-instructions behind every fourth MFMA
+        const bool more2 = (c + 2 < nch) && !(dbg & 1);
+        const bool more1 = (c + 1 < nch);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            mma_x_row(fa0, fb0, i);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more2 && !(dbg & 1)) issue_dma_piece(c + 2, i);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < NSLOT; ++q) {
+            GPMI_MFMA_X(fa0, fb0, 2 * q);
+            GPMI_MFMA_X(fa0, fb0, 2 * q + 1);
+            GPMI_FENCE();
+            if (more2 && q < DPW) issue_dma_one(c + 2, q);
+            GPMI_FENCE();
         }
-        read_frags(c, 1, fa1, fb1);          // lands under the next 16 MFMAs
-        __builtin_amdgcn_sched_barrier(0);
-        mma_y(fa0, fb0);
-        __builtin_amdgcn_sched_barrier(0);
-        // stage c+1 landed (only the pieces of c+2 may still be in flight); all my LDS reads done
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+            GPMI_MFMA_Y(fa0, fb0, 2 * q);
+            GPMI_MFMA_Y(fa0, fb0, 2 * q + 1);
+            GPMI_FENCE();
+            if (q < NFR) read_one(c, 1, q, fa1, fb1);
+            if (NSLOT < NFR && q + NSLOT < NFR) read_one(c, 1, q + NSLOT, fa1, fb1);
+            GPMI_FENCE();
+        }
         if (!(dbg & 2)) {
-            if (more2 && !(dbg & 1)) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            if (more2) {
+                if constexpr (DPW == 8) asm volatile("s_waitcnt vmcnt(8)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_x(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c + 1 < nch) read_frags(c + 1, 0, fa0, fb0);   // under the last 16 MFMAs of the step
-        __builtin_amdgcn_sched_barrier(0);
-        mma_y(fa1, fb1);
-        __builtin_amdgcn_sched_barrier(0);
+        GPMI_FENCE();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) GPMI_MFMA_X(fa1, fb1, t);
+        GPMI_FENCE();
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+            GPMI_MFMA_Y(fa1, fb1, 2 * q);
+            GPMI_MFMA_Y(fa1, fb1, 2 * q + 1);
+            GPMI_FENCE();
+            if (more1 && q < NFR) read_one(c + 1, 0, q, fa0, fb0);
+            if (more1 && NSLOT < NFR && q + NSLOT < NFR) read_one(c + 1, 0, q + NSLOT, fa0, fb0);
+            GPMI_FENCE();
+        }
     }
+#undef GPMI_MFMA_X
+#undef GPMI_MFMA_Y
+#undef GPMI_FENCE
 
-    // epilogue: C -= acc in 16-row bands; the loads of band i+1 are issued before the
-    // stores of band i (nothing else runs on this SIMD, so a band must not cost a round trip)
+    if (DBG && (dbg & 16)) st2 = clock64();
+    // epilogue: C -= acc in 16-row bands (nothing else runs on this SIMD, so it must not
+    // cost a memory round trip per band)
     double* Cg = p.C + ((int64_t)ti * DMA_TM + wr) * p.ldc + (int64_t)tj * DMA_TN + wc;
     auto c_ptr = [&](int i, int j, int v) { return Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr; };
     if (DBG && (dbg & 8)) {
         double t = 0.;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 123.456) Cg[0] = t;
         return;
     }
-    double cv[2][4][4];
+    // up to three bands of loads in flight (the fragment registers are dead by now), so
+    // the whole read-modify-write costs about one memory round trip plus issue time
+    constexpr int NB3 = MI < 3 ? MI : 3;
+    double cv[NB3][4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) cv[0][j][v] = *c_ptr(0, j, v);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (i + 1 < 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) cv[(i + 1) & 1][j][v] = *c_ptr(i + 1, j, v);
-        }
+    for (int i = 0; i < NB3; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) *c_ptr(i, j, v) = cv[i & 1][j][v] - acc[i][j][v];
+            for (int v = 0; v < 4; ++v) cv[i][j][v] = *c_ptr(i, j, v);
+    if (DBG && (dbg & 16)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st3 = clock64();
+    }
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *c_ptr(i, j, v) = cv[i % NB3][j][v] - acc[i][j][v];
+        if (i == 0 && MI > 3) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) cv[0][j][v] = *c_ptr(3, j, v);
+        }
+    }
+    if (DBG && (dbg & 16)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st4 = clock64();
+        if (lane == 0 && blockIdx.x < 4096) {
+            unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + (wave & 3)) * 4;
+            o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st3 - st2; o[3] = st4 - st3;
+        }
     }
 }
+
+unsigned long long* g_gemm_stamps = nullptr;
+int g_gemm_dma_waves = 8;   // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
 
 bool gemm_dma_eligible(const GemmArgs& a) {
     return a.mode == 0 && a.N % 128 == 0 && a.M % 128 == 0 && a.K % 16 == 0 && a.K >= 32;
@@ -261,13 +323,22 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     constexpr size_t lds = (size_t)DMA_STAGES * DMA_STAGE_SLOTS * 16;
     static bool attr = false;
     if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     p.dbg = g_gemm_dbg & 0xff;
-    if (p.dbg) hipLaunchKernelGGL(gemm_nt_dma_kernel<true>, dim3(nblocks), dim3(256), lds, s, p);
-    else hipLaunchKernelGGL(gemm_nt_dma_kernel<false>, dim3(nblocks), dim3(256), lds, s, p);
+    p.stamps = g_gemm_stamps;
+    p.stagger = (g_gemm_stagger && (int64_t)p.Tm * p.Tn >= 1024) ? 1 : 0;
+    if (g_gemm_dma_waves == 8) {
+        if (p.dbg) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, true>), dim3(nblocks), dim3(512), lds, s, p);
+        else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, false>), dim3(nblocks), dim3(512), lds, s, p);
+    } else {
+        if (p.dbg) hipLaunchKernelGGL((gemm_nt_dma_kernel<4, true>), dim3(nblocks), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_nt_dma_kernel<4, false>), dim3(nblocks), dim3(256), lds, s, p);
+    }
     return hipGetLastError();
 }
 

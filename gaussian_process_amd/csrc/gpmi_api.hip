@@ -423,6 +423,9 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_dma_waves")) {
+        if (value != 4 && value != 8) return fail_arg("gemm_dma_waves must be 4 or 8");
+        g_gemm_dma_waves = (int)value;
     } else if (!strcmp(name, "gemm_dma")) {
         g_gemm_use_dma = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_stagger_rule")) {
@@ -771,6 +774,12 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
         GemmArgs g;
         g.C = C.as<double>(); g.A = A.as<double>(); g.B = B.as<double>();
         g.ldc = ldc; g.lda = g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = 0;
+        DevBuf stamps;
+        if (variant & 16) {
+            if ((e = stamps.ensure(4096 * 16 * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
+            (void)hipMemsetAsync(stamps.p, 0, 4096 * 16 * 8, s);
+            g_gemm_stamps = stamps.as<unsigned long long>();
+        }
         g_gemm_dbg = variant;
         e = launch_gemm_nt(s, g);
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
@@ -785,6 +794,18 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
         (void)hipEventElapsedTime(&ms, ea, eb);
         out[1] = ms / reps;
         out[0] = gemm_nt_flops(g) / (out[1] * 1e-3) / 1e12;
+        if (variant & 16) {
+            std::vector<unsigned long long> h(4096 * 16);
+            (void)hipMemcpy(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[4] = {0, 0, 0, 0};
+            int cnt = 0;
+            for (size_t i = 0; i < h.size(); i += 4)
+                if (h[i + 1]) { for (int q = 0; q < 4; ++q) sum[q] += (double)h[i + q]; ++cnt; }
+            if (cnt) fprintf(stderr, "[gemm stamps] waves %d: prologue %.0f  loop %.0f  epilogue-loads %.0f  epilogue-stores %.0f cycles\n",
+                             cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt);
+            g_gemm_stamps = nullptr;
+            stamps.release();
+        }
     } while (0);
     g_gemm_dbg = 0;
     if (ea) (void)hipEventDestroy(ea);
