@@ -81,7 +81,8 @@ def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,N,d,n,nb,la", [(2, 1500, 8, 200, 256, 1), (3, 2100, 8, 130, 128, 1),
                                                 (2, 4096, 8, 512, 512, 1), (2, 1500, 8, 200, 256, 0),
-                                                (1, 1300, 8, 100, 256, 1)])
+                                                (1, 1300, 8, 100, 256, 1),
+                                                (2, 12288, 8, 256, 512, 1)])   # large enough for the LDS-DMA GEMM + row map
 def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
     res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb, lookahead=la)
     _check(res, oracle, N, d, n)
