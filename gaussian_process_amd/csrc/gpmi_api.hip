@@ -940,6 +940,21 @@ int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_
     return GPMI_OK;
 }
 
+int gpmi_dev_gemv_t(void* stream, const double* A_dev, int64_t ld, int64_t nrows, int64_t ncols,
+                    const double* x_dev, double* y_dev, double* scratch_dev) {
+    if (!y_dev || !scratch_dev || (nrows > 0 && (!A_dev || !x_dev))) return fail_arg("gpmi_dev_gemv_t: null pointer");
+    if (nrows < 0 || ncols < 0) return fail_arg("gpmi_dev_gemv_t: negative size");
+    HIP_TRY(launch_gemv_t((hipStream_t)stream, A_dev, ld, nrows, ncols, x_dev, y_dev, scratch_dev));
+    return GPMI_OK;
+}
+
+int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_dev, int64_t n) {
+    if (!L_dev || !b_dev) return fail_arg("gpmi_dev_trsv_lt: null pointer");
+    if (n <= 0 || n % IB) return fail_arg("gpmi_dev_trsv_lt: n must be a positive multiple of 64");
+    HIP_TRY(launch_trsv_lt((hipStream_t)stream, L_dev, ld, b_dev, n));
+    return GPMI_OK;
+}
+
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
                       const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
     if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");

@@ -147,6 +147,42 @@ hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b,
     return hipGetLastError();
 }
 
+// ---- y = A^T x for a row-major nrows x ncols block (distributed backward solve) -----------
+// grid (column chunks, row chunks of 64); partial sums per row chunk, then a fixed-order sum
+__global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* A, int64_t ld, int64_t nrows,
+                                                              int64_t ncols, const double* x, double* part) {
+    __shared__ double xs[64];
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    const int nr = (int)((nrows - r0) < 64 ? (nrows - r0) : 64);
+    if (threadIdx.x < 64) xs[threadIdx.x] = (threadIdx.x < nr) ? x[r0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncols) return;
+    const double* col = A + r0 * ld + c;
+    double s = 0.;
+    for (int r = 0; r < nr; ++r) s = fma(col[(int64_t)r * ld], xs[r], s);
+    part[(int64_t)blockIdx.y * ncols + c] = s;
+}
+
+__global__ void gemv_t_sum_kernel(const double* part, int64_t nchunks, int64_t ncols, double* y) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    double s = 0.;
+    for (int64_t q = 0; q < nchunks; ++q) s += part[q * ncols + c];
+    y[c] = s;
+}
+
+hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nrows, int64_t ncols,
+                         const double* x, double* y, double* scratch) {
+    if (ncols <= 0) return hipSuccess;
+    const int64_t nchunks = (nrows + 63) / 64;
+    if (nchunks > 0)
+        hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((ncols + 255) / 256), (unsigned)nchunks), dim3(256), 0, s,
+                           A, ld, nrows, ncols, x, scratch);
+    hipLaunchKernelGGL(gemv_t_sum_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, scratch, nchunks, ncols, y);
+    return hipGetLastError();
+}
+
 // ---- fills / extraction --------------------------------------------------------
 __global__ void fill_rows_kernel(double* A, int64_t ld, int64_t ncols, double value) {
     double* row = A + (int64_t)blockIdx.y * ld;

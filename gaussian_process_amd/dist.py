@@ -101,6 +101,15 @@ class HipBlockOps:
         check(self.lib.gpmi_dev_row_dots(self._stream(), self._p(V), self._ld(V), V.shape[0], ncols,
                                          self._p(m), self._p(dot), self._p(sq)))
 
+    def gemv_t(self, A, x, y, scratch):
+        check(self.lib.gpmi_dev_gemv_t(self._stream(), self._p(A) if A is not None else None,
+                                       self._ld(A) if A is not None else 0,
+                                       A.shape[0] if A is not None else 0, y.shape[0],
+                                       self._p(x) if x is not None else None, self._p(y), self._p(scratch)))
+
+    def trsv_lt(self, L, b):
+        check(self.lib.gpmi_dev_trsv_lt(self._stream(), self._p(L), self._ld(L), self._p(b), b.shape[0]))
+
     def sync(self):
         torch.cuda.synchronize(self.device)
 
@@ -466,6 +475,59 @@ class DistGP:
     def predict(self, Xs, want_sd=True):
         self.set_test(Xs)
         return self.predict_resident(want_sd)
+
+    # ------------------------------------------------------------------ alpha
+    def alpha(self):
+        """alpha = solve(L.T, m) (GP_regression.py:140) with L distributed by row blocks.
+        Blocks from the bottom up: every rank forms the contribution of its rows below
+        block k, sum_j L_jk^T alpha_j (its own alpha_j, which it solved itself); the
+        contributions are gathered and summed in rank order; the owner of block k solves
+        L_kk^T alpha_k = m_k - sum.  One 8*G*nb-byte all-gather per block: latency-bound,
+        L never moves.  Returns the full alpha (N,) on every rank."""
+        if not self.have_factor:
+            raise ValueError("no factorisation resident (call factorize)")
+        ops, NB, G, A, T = self.ops, self.NB, self.G, self.A, self.T
+        aloc = self._tensor(max(self.nloc, 1) * NB)
+        aloc.zero_()
+        part = self._tensor(NB)
+        allp = self._tensor(G * NB)
+        rhs = self._tensor(NB)
+        scratch = self._tensor(max((self.nloc * NB + 63) // 64, 1) * NB)
+        for k in range(T - 1, -1, -1):
+            c0 = k * NB
+            ls = self._lstart(k)
+            r0, r1 = ls * NB, self.nloc * NB
+            if r1 > r0:
+                ops.gemv_t(A[r0:r1, c0:c0 + NB], aloc[r0:r1], part, scratch)
+            else:
+                part.zero_()
+            if G > 1:
+                dist.all_gather_into_tensor(allp, part, group=self.group)
+            else:
+                allp.copy_(part)
+            if self.rank == k % G:
+                li = k // G
+                rhs.copy_(self.m[c0:c0 + NB])
+                P = allp.view(G, NB)
+                for r in range(G):                     # fixed order
+                    rhs.sub_(P[r])
+                ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs)
+                aloc[li * NB:(li + 1) * NB].copy_(rhs)
+        # assemble the full vector in natural block order
+        cmax = max(self._nblocks(r) for r in range(G))
+        send = self._tensor(cmax * NB)
+        send.zero_()
+        send[:self.nloc * NB].copy_(aloc[:self.nloc * NB])
+        if G > 1:
+            recv = self._tensor(G * cmax * NB)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+        else:
+            recv = send
+        R = recv.view(G, cmax, NB).cpu().numpy()
+        out = np.empty(self.Np)
+        for b in range(T):
+            out[b * NB:(b + 1) * NB] = R[b % G, b // G]
+        return out[:self.N].copy()
 
     def fit(self, X, y, sigma, ell, noise_var):
         self.set_train(X, y)

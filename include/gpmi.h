@@ -185,6 +185,13 @@ int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const doub
  * (skipped if x_dev is NULL): the per-rank pieces of the log-marginal-likelihood */
 int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
                            int64_t nx, double* out2_dev);
+/* y[c] = sum_r A[r][c] * x[r] for a row-major nrows x ncols block (fixed summation order);
+ * scratch: ceil(nrows/64) * ncols doubles.  Piece of the distributed backward solve
+ * (GP_regression.py:140): a rank's contribution L_jk^T alpha_j of its rows below block k. */
+int gpmi_dev_gemv_t(void* stream, const double* A_dev, int64_t ld, int64_t nrows, int64_t ncols,
+                    const double* x_dev, double* y_dev, double* scratch_dev);
+/* backward substitution L^T x = b on an n x n lower block (x overwrites b), n % 64 == 0 */
+int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_dev, int64_t n);
 /* out[i] = sum_j V[i][j]*m[j] ; out2[i] = sum_j V[i][j]^2  (partial sums over
  * the columns this rank owns), i < nrows, j < ncols */
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows,

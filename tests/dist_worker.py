@@ -29,6 +29,7 @@ def main():
     X, y, Xs = O.synthetic_problem(N, d, n, seed=77)
     lml = gp.fit(X, y, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
     mu, var = gp.predict(Xs, want_sd=False)
+    alpha = gp.alpha()
     lml2 = gp.factorize(1.3, 1.5 * np.sqrt(d / 8.0), 1e-3)        # refit on resident data
     mu2, sd2 = gp.predict_resident(want_sd=True)
     raised = 0
@@ -55,7 +56,7 @@ def main():
         evaluate = ctx.lml_batch
     blml, bst = sharded_lml_batch(triples, evaluate)
     np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised,
-             blml=blml, bst=bst, triples=triples)
+             blml=blml, bst=bst, triples=triples, alpha=alpha)
     dist.barrier()
     dist.destroy_process_group()
 

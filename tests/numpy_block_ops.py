@@ -91,5 +91,12 @@ class NumpyBlockOps:
         self._a(dot)[:] = v @ self._a(m)[:ncols]
         self._a(sq)[:] = (v * v).sum(1)
 
+    def gemv_t(self, A, x, y, scratch):
+        self._a(y)[:] = self._a(A).T @ self._a(x) if A is not None else 0.0
+
+    def trsv_lt(self, L, b):
+        bb = self._a(b)
+        bb[:] = sla.solve_triangular(np.tril(self._a(L)), bb, lower=True, trans='T', check_finite=False)
+
     def sync(self):
         pass

@@ -48,6 +48,7 @@ def _check(res, oracle, N, d, n):
         assert abs(r["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
         assert np.max(np.abs(r["mu"] - ref["mu"])) <= 1e-9
         assert np.max(np.abs(r["var"] - ref["var"])) <= 1e-10
+        assert np.max(np.abs(r["alpha"] - ref["alpha"])) <= 1e-8 * np.max(np.abs(ref["alpha"]))
         assert abs(r["lml2"] - ref2["lml"]) <= 1e-10 * abs(ref2["lml"])
         assert np.max(np.abs(r["mu2"] - ref2["mu"])) <= 1e-9
         assert np.max(np.abs(r["sd2"] - np.sqrt(ref2["var"]))) <= 1e-9
@@ -60,7 +61,7 @@ def _check(res, oracle, N, d, n):
                 want = want_batch[t]
                 assert abs(r["blml"][t] - want) <= 1e-10 * abs(want) and r["bst"][t] == 0
     for r in res[1:]:                      # every rank returns the same bits
-        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml"):
+        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml", "alpha"):
             assert np.array_equal(r[key], res[0][key], equal_nan=True), key
 
 
