@@ -3,8 +3,10 @@
 Same names, positional order, return shapes/dtypes and hard-coded constants as
 /root/reference/GP_regression.py (s = 0.0005 and sigma = 1 inside `prediction`,
 :120-121; jitter 1e-6, :154); the arithmetic runs on the MI355X through
-libgpmi355x.so.  Only the squared-exponential kernel is in scope
-(BASELINE.json north_star): 'lin' / 'per' raise.
+libgpmi355x.so.  The squared-exponential kernel is the optimised path
+(BASELINE.json north_star); the reference's linear and periodic kernels
+ run through the same factorisation with a plain
+kernel-matrix build.
 """
 from __future__ import annotations
 
@@ -40,11 +42,32 @@ def dataset_generator(N, n):
     return f, X_train, y_train, X_test
 
 
-def _rbf_only(kernel_choice):
-    if kernel_choice != 'rbf':
-        raise NotImplementedError(
-            "kernel_choice=%r: only the squared-exponential ('rbf') path is implemented on the "
-            "MI355X (linear / periodic kernels are out of scope, SURVEY.md section 8f row f4)" % (kernel_choice,))
+def lin_kernel(a, b, c):
+    """linear kernel np.dot(a - c, b.T - c), reference GP_regression.py:22-33"""
+    return default_context().cov('lin', a, b, c)
+
+
+def per_kernel(a, b, parameters):
+    """periodic kernel exp(-2 sin(pi |a-b| / p)^2 / l^2) on 1-D inputs, parameters = (p, l);
+    reference GP_regression.py:36-50"""
+    p, l = parameters
+    return default_context().cov('per', a, b, p, l)
+
+
+def _select_kernel(ctx, kernel_choice, parameter, sigma):
+    """kernel_choice / parameter conventions of prediction() (GP_regression.py:125-136):
+    'rbf': l; 'lin': the offset c; 'per': the tuple (p, l)."""
+    if kernel_choice == 'rbf':
+        ctx.set_kernel('rbf')
+        return sigma, parameter
+    if kernel_choice == 'lin':
+        ctx.set_kernel('lin', parameter)
+        return 1.0, 1.0
+    if kernel_choice == 'per':
+        p, l = parameter
+        ctx.set_kernel('per', p, l)
+        return 1.0, 1.0
+    raise ValueError("kernel_choice must be 'rbf', 'lin' or 'per', got %r" % (kernel_choice,))
 
 
 def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIGMA_F,
@@ -56,22 +79,28 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
     would (K + sI at :138, posterior covariance at :154).  The normals of :155
     are drawn on the host from np.random in the reference's order.
     """
-    _rbf_only(kernel_choice)
     ctx = ctx or default_context()
-    ctx.fit(X_train, y_train, sigma, l, noise_var)        # :126,138-140
-    mu_post, stand_devi = ctx.predict(X_test, want_sd=True)  # :127,143-148
-    n = mu_post.shape[0]
-    L_ = ctx.post_chol(jitter)                            # :154
+    try:
+        sg, ll = _select_kernel(ctx, kernel_choice, l, sigma)  # :125-136
+        ctx.fit(X_train, y_train, sg, ll, noise_var)          # :126,138-140
+        mu_post, stand_devi = ctx.predict(X_test, want_sd=True)  # :127,143-148
+        n = mu_post.shape[0]
+        L_ = ctx.post_chol(jitter)                            # :154
+    finally:
+        ctx.set_kernel('rbf')
     f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(n, num_fun)))  # :155
     return mu_post, stand_devi, f_post_fun
 
 
 def f_prior(X_test, mu_prior, kernel_choice, kernel_parameter, num_fun, *, ctx=None):
     """GP prior samples, reference GP_regression.py:71-92 (s = 0.0005, sigma = 1)."""
-    _rbf_only(kernel_choice)
     ctx = ctx or default_context()
     X_test = np.asarray(X_test, dtype=np.float64)
     num_test = len(X_test)
-    ctx.fit(X_test, np.zeros(num_test), SIGMA_F, kernel_parameter, NOISE_VAR)   # :90
-    B = ctx.factor()
+    try:
+        sg, ll = _select_kernel(ctx, kernel_choice, kernel_parameter, SIGMA_F)      # :84-89
+        ctx.fit(X_test, np.zeros(num_test), sg, ll, NOISE_VAR)                      # :90
+        B = ctx.factor()
+    finally:
+        ctx.set_kernel('rbf')
     return mu_prior + np.dot(B, np.random.normal(size=(num_test, num_fun)))     # :91

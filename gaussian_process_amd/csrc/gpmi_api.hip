@@ -81,10 +81,13 @@ struct gpmi_ctx {
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
     bool have_train = false, have_factor = false;
     double sig2 = 1.0, coef = -0.5;
+    int kind = 0;            // covariance function: 0 rbf, 1 linear, 2 periodic (gpmi_set_kernel)
+    double kp0 = 0., kp1 = 0.;
     DevBuf X, y, A, info, red;
     // test set
     int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
     bool have_test = false, have_v = false;
+    std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     DevBuf Xs, V, P, vec, dense;
     // timers
     std::vector<hipEvent_t> ev_pool;
@@ -264,6 +267,11 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     return hipSuccess;
 }
 
+void set_kernel_args(const gpmi_ctx* c, RbfArgs& r) {
+    r.coef = c->coef; r.sig2 = c->sig2;
+    r.kind = c->kind; r.kp0 = c->kp0; r.kp1 = c->kp1;
+}
+
 int ensure_train_buffers(gpmi_ctx* c) {
     c->Np = round_up(c->N, TILE);
     c->ldA = c->Np + c->ld_pad;
@@ -278,8 +286,10 @@ int ensure_train_buffers(gpmi_ctx* c) {
 int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
                    int64_t* bad_pivot) {
     if (!c->have_train) return fail_arg("gpmi_factorize: no training set (call gpmi_set_train)");
-    if (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma) || std::isnan(noise_var))
+    if (c->kind == 0 && (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma)))
         return fail_arg("gpmi_factorize: ell must be non-zero and hyper-parameters finite");
+    if (std::isnan(noise_var)) return fail_arg("gpmi_factorize: noise_var is NaN");
+    if (c->kind == 2 && c->d != 1) return fail_arg("gpmi_factorize: the periodic kernel is 1-D only (GP_regression.py:48)");
     int rc = ensure_train_buffers(c);
     if (rc) return rc;
     hipStream_t s = c->stream;
@@ -297,7 +307,8 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     RbfArgs r;
     r.A = r.B = c->X.as<double>();
     r.nA = r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->Np; r.ncols = c->Np;
-    r.coef = c->coef; r.sig2 = c->sig2; r.diag_add = noise_var; r.symmetric = 1;
+    set_kernel_args(c, r);
+    r.diag_add = noise_var; r.symmetric = 1;
     r.out = A; r.ld = c->ldA;
     HIP_TRY(launch_rbf(s, r));
     // the augmented rows: y then zeros
@@ -452,6 +463,15 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
     return GPMI_OK;
 }
 
+int gpmi_set_kernel(gpmi_ctx* c, int kind, double p0, double p1) {
+    if (!c) return fail_arg("gpmi_set_kernel: null context");
+    if (kind < 0 || kind > 2) return fail_arg("gpmi_set_kernel: kind must be 0 (rbf), 1 (linear) or 2 (periodic)");
+    if (kind == 2 && (!(p0 != 0.0) || !(p1 != 0.0))) return fail_arg("gpmi_set_kernel: period and lengthscale must be non-zero");
+    c->kind = kind; c->kp0 = p0; c->kp1 = p1;
+    c->have_factor = c->have_v = false;
+    return GPMI_OK;
+}
+
 int gpmi_sync(gpmi_ctx* c) {
     if (!c) return fail_arg("gpmi_sync: null context");
     HIP_TRY(hipSetDevice(c->device));
@@ -459,11 +479,23 @@ int gpmi_sync(gpmi_ctx* c) {
     return GPMI_OK;
 }
 
+int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
+             double p0, double p1, double* out);
+
 int gpmi_rbf(gpmi_ctx* c, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
              double sigma, double ell, double* out) {
+    return gpmi_cov(c, 0, a, N, b, M, d, sigma, ell, out);
+}
+
+int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
+             double p0, double p1, double* out) {
+    const double sigma = p0, ell = p1;
     if (!c || !a || !b || !out) return fail_arg("gpmi_rbf: null argument");
     if (N < 0 || M < 0 || d <= 0) return fail_arg("gpmi_rbf: bad dimensions");
-    if (!(ell != 0.0)) return fail_arg("gpmi_rbf: ell must be non-zero");
+    if (kind < 0 || kind > 2) return fail_arg("gpmi_cov: kind must be 0, 1 or 2");
+    if (kind == 0 && !(ell != 0.0)) return fail_arg("gpmi_rbf: ell must be non-zero");
+    if (kind == 2 && (d != 1 || !(p0 != 0.0) || !(p1 != 0.0)))
+        return fail_arg("gpmi_cov: the periodic kernel is 1-D with non-zero period and lengthscale");
     if (N == 0 || M == 0) return GPMI_OK;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -486,7 +518,8 @@ int gpmi_rbf(gpmi_ctx* c, const double* a, int64_t N, const double* b, int64_t M
             RbfArgs r;
             r.A = da.as<double>(); r.B = db.as<double>();
             r.nA = N; r.nB = M; r.d = d; r.row0 = r0; r.nrows = round_up(rows, TILE); r.ncols = Mp;
-            r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
+            r.coef = (kind == 0) ? -.5 * (1 / (ell * ell)) : 0.; r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
+            r.kind = kind; r.kp0 = p0; r.kp1 = p1;
             r.out = dout.as<double>(); r.ld = ld;
             if ((e = launch_rbf(s, r)) != hipSuccess) { rc = fail_runtime(e, "rbf kernel"); break; }
             if ((e = hipMemcpy2DAsync(out + r0 * M, (size_t)M * 8, dout.p, (size_t)ld * 8, (size_t)M * 8,
@@ -594,6 +627,7 @@ int gpmi_set_test(gpmi_ctx* c, const double* Xs, int64_t n) {
     HIP_TRY(c->Xs.ensure((size_t)n * c->d * 8));
     HIP_TRY(hipMemcpyAsync(c->Xs.p, Xs, (size_t)n * c->d * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    c->hXs.assign(Xs, Xs + (size_t)n * c->d);
     c->n = n;
     c->np_ = round_up(n, TILE);
     c->have_test = true;
@@ -617,7 +651,8 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     RbfArgs r;
     r.A = c->Xs.as<double>(); r.B = c->X.as<double>();
     r.nA = c->n; r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->np_; r.ncols = c->Np;
-    r.coef = c->coef; r.sig2 = c->sig2; r.diag_add = 0.; r.symmetric = 0;
+    set_kernel_args(c, r);
+    r.diag_add = 0.; r.symmetric = 0;
     r.out = V; r.ld = c->ldV;
     HIP_TRY(launch_rbf(s, r));
     c->span_end(sp);
@@ -640,7 +675,16 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     for (int64_t i = 0; i < c->n; ++i) {
         if (mu) mu[i] = h[i];
         if (out2) {
-            const double var = c->sig2 - h[c->np_ + i];   // diag(K_ss) == sigma^2 exactly (GP_regression.py:147)
+            double kss = c->sig2;                          // diag(K_ss) == sigma^2 exactly for the RBF (GP_regression.py:147)
+            if (c->kind == 2) kss = 1.0;                   // periodic: exp(0)
+            else if (c->kind == 1) {                       // linear: (x - c).(x - c)
+                kss = 0.0;
+                for (int64_t k = 0; k < c->d; ++k) {
+                    const double e = c->hXs[(size_t)i * c->d + k] - c->kp0;
+                    kss = kss + e * e;
+                }
+            }
+            const double var = kss - h[c->np_ + i];
             out2[i] = want_sd ? std::sqrt(var) : var;      // sqrt(<0) -> NaN like np.sqrt (:148)
         }
     }
@@ -669,7 +713,8 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     RbfArgs r;   // K_ss + jitter*I, lower tiles (GP_regression.py:128,154)
     r.A = r.B = c->Xs.as<double>();
     r.nA = r.nB = n; r.d = c->d; r.row0 = 0; r.nrows = np_; r.ncols = np_;
-    r.coef = c->coef; r.sig2 = c->sig2; r.diag_add = jitter; r.symmetric = 1;
+    set_kernel_args(c, r);
+    r.diag_add = jitter; r.symmetric = 1;
     r.out = P; r.ld = c->ldP;
     HIP_TRY(launch_rbf(s, r));
     GemmArgs g;  // P -= v^T v  (rows of V are the columns of v)

@@ -63,6 +63,11 @@ struct RbfArgs {
     int symmetric;     // 1: A==B, lower tiles only, identity padding
     double* out;       // nrows x ld, out(0,0) is element (row0, 0)
     int64_t ld;
+    // covariance function: 0 squared-exponential (coef, sig2 above);
+    // 1 linear  sum_k (a_k - c)(b_k - c), c = kp0            (GP_regression.py:22-33)
+    // 2 periodic exp(-2 sin^2(pi |a-b| / p) / l^2), p = kp0, l = kp1, d == 1 (GP_regression.py:36-50)
+    int kind = 0;
+    double kp0 = 0., kp1 = 0.;
 };
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a);
 

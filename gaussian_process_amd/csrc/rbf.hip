@@ -39,6 +39,8 @@ struct RbfDev {
     int tri;               // triangular tile enumeration (symmetric, row0 == 0)
     double* __restrict__ out;
     int64_t ld;
+    int kind;
+    double kp0, kp1;
 };
 
 #pragma clang fp contract(off)
@@ -154,12 +156,19 @@ __device__ __forceinline__ bool rbf_map_tile(const RbfDev& p, int& ti, int& tj) 
     return !(p.symmetric && (int64_t)tj * RT > p.row0 + (int64_t)ti * RT + RT - 1);
 }
 
+__device__ __forceinline__ void cov_store(const RbfDev& p, int64_t gr, int64_t gc, double v0, double v1,
+                                          double* dst);
+
 __device__ __forceinline__ void rbf_finish(const RbfDev& p, int64_t gr, int64_t gc, double s0, double s1,
                                            double* dst) {
     double e0, e1;
     exp_pair(p.coef * s0, p.coef * s1, e0, e1);
-    double v0 = p.sig2 * e0;
-    double v1 = p.sig2 * e1;
+    cov_store(p, gr, gc, p.sig2 * e0, p.sig2 * e1, dst);
+}
+
+// diagonal term, identity / zero padding, 16-byte store of a column pair
+__device__ __forceinline__ void cov_store(const RbfDev& p, int64_t gr, int64_t gc, double v0, double v1,
+                                          double* dst) {
     if (p.symmetric) {
         if (gr == gc) v0 = v0 + p.diag_add;
         if (gr == gc + 1) v1 = v1 + p.diag_add;
@@ -310,6 +319,40 @@ __global__ __launch_bounds__(256) void rbf_naive_kernel(const RbfDev p) {
     }
 }
 
+// The reference's other two covariance functions, one column pair per
+// thread straight from global memory: these matrices are built once per fit, the work is in
+// the factorisation.
+__device__ __forceinline__ double cov_other(const RbfDev& p, const double* a, const double* b) {
+    if (p.kind == 1) {                         // lin_kernel: np.dot(a - c, b.T - c)
+        double s = 0.0;
+        for (int k = 0; k < p.d; ++k) s = s + (a[k] - p.kp0) * (b[k] - p.kp0);
+        return s;
+    }
+    // per_kernel (1-D): exp(-2 * sin(pi * |a-b| / p)**2 / l**2), evaluated in the reference's order
+    const double t = fabs(a[0] - b[0]);
+    const double sn = sin(M_PI * t / p.kp0);
+    return exp(-2.0 * (sn * sn) / (p.kp1 * p.kp1));
+}
+
+__global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
+    int ti, tj;
+    if (!rbf_map_tile(p, ti, tj)) return;
+    const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+    const int64_t gcol0 = (int64_t)tj * RT;
+    const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int64_t gc = gcol0 + 2 * cp;
+    const int d = p.d;
+    for (int r = 0; r < 32; ++r) {
+        const int64_t gr = grow0 + 32 * rg + r;
+        double v0 = 0., v1 = 0.;
+        if (gr < p.nA) {
+            if (gc < p.nB) v0 = cov_other(p, p.A + gr * d, p.B + gc * d);
+            if (gc + 1 < p.nB) v1 = cov_other(p, p.A + gr * d, p.B + (gc + 1) * d);
+        }
+        cov_store(p, gr, gc, v0, v1, p.out + ((int64_t)ti * RT + 32 * rg + r) * p.ld + gc);
+    }
+}
+
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     if (a.nrows <= 0 || a.ncols <= 0) return hipSuccess;
     if (a.nrows % RT || a.ncols % RT || a.d <= 0) return hipErrorInvalidValue;
@@ -318,10 +361,16 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     p.Tm = (int)(a.nrows / RT); p.Tn = (int)(a.ncols / RT);
     p.coef = a.coef; p.sig2 = a.sig2; p.diag_add = a.diag_add; p.symmetric = a.symmetric;
     p.out = a.out; p.ld = a.ld;
+    p.kind = a.kind; p.kp0 = a.kp0; p.kp1 = a.kp1;
+    if (a.kind < 0 || a.kind > 2 || (a.kind == 2 && a.d != 1)) return hipErrorInvalidValue;
     p.tri = (a.symmetric && a.row0 == 0 && p.Tm == p.Tn) ? 1 : 0;
     const int64_t nblk = p.tri ? (int64_t)p.Tm * (p.Tm + 1) / 2 : (int64_t)p.Tm * p.Tn;
     dim3 grid((unsigned)nblk), block(256);
     const size_t lds = (size_t)2 * RT * a.d * sizeof(double);
+    if (a.kind != 0) {
+        hipLaunchKernelGGL(cov_other_kernel, grid, block, 0, s, p);
+        return hipGetLastError();
+    }
 #define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_regs_kernel<DD>, grid, block, 0, s, p.A, p.B, p.out, p); break
     if (a.d > LDS_MAXD) {
         hipLaunchKernelGGL(rbf_naive_kernel, grid, block, 0, s, p);

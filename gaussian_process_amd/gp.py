@@ -92,6 +92,24 @@ class GPContext:
                                  scalar(sigma, "sigma"), scalar(l, "l"), ptr(out)))
         return out
 
+    KINDS = {"rbf": 0, "lin": 1, "per": 2}
+
+    def cov(self, kind, a, b, p0, p1=0.0):
+        """kernel matrix of the reference's covariance functions: 'rbf' (p0 = sigma, p1 = l),
+        'lin' (p0 = c), 'per' (p0 = period, p1 = lengthscale; 1-D inputs)"""
+        a = as_f64(a, 2, "a")
+        b = as_f64(b, 2, "b")
+        if a.shape[1] != b.shape[1]:
+            raise ValueError("a and b must have the same number of columns (d): %s vs %s" % (a.shape, b.shape))
+        out = np.empty((a.shape[0], b.shape[0]), dtype=np.float64)
+        check(self._lib.gpmi_cov(self._h, self.KINDS[kind], ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
+                                 scalar(p0, "p0"), scalar(p1, "p1"), ptr(out)))
+        return out
+
+    def set_kernel(self, kind, p0=0.0, p1=0.0):
+        """covariance function of the following fit / predict calls (kernel_choice of prediction())"""
+        check(self._lib.gpmi_set_kernel(self._h, self.KINDS[kind], scalar(p0, "p0"), scalar(p1, "p1")))
+
     # ---- fit --------------------------------------------------------------------------
     def set_train(self, X, y):
         X = as_f64(X, 2, "X_train")

@@ -73,6 +73,17 @@ int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);
 int gpmi_rbf(gpmi_ctx* ctx, const double* a, int64_t N, const double* b, int64_t M,
              int64_t d, double sigma, double ell, double* out);
 
+/* The reference's other covariance functions, same layout as gpmi_rbf:
+ *   kind 0: RBF_kernel (p0 = sigma, p1 = l)                               GP_regression.py:8-19
+ *   kind 1: lin_kernel(a, b, c): np.dot(a - c, b.T - c), p0 = c            GP_regression.py:22-33
+ *   kind 2: per_kernel(a, b, (p, l)): exp(-2 sin(pi|a-b|/p)^2 / l^2), d = 1, p0 = p, p1 = l   :36-50 */
+int gpmi_cov(gpmi_ctx* ctx, int kind, const double* a, int64_t N, const double* b, int64_t M,
+             int64_t d, double p0, double p1, double* out);
+/* Covariance function used by gpmi_factorize / gpmi_predict / gpmi_post_chol from now on
+ * (kernel_choice of prediction(), GP_regression.py:125-136).  kind 0 (default) takes sigma and l
+ * from gpmi_factorize; kinds 1, 2 take (p0, p1) as above and ignore them. */
+int gpmi_set_kernel(gpmi_ctx* ctx, int kind, double p0, double p1);
+
 /* Copy the training set to the device (X: N x d, y: N).  Replaces nothing in
  * the reference (it has no device); separates PCIe from the timed path. */
 int gpmi_set_train(gpmi_ctx* ctx, const double* X, int64_t N, int64_t d, const double* y);

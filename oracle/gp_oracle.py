@@ -52,6 +52,43 @@ def RBF_kernel_chunked(a, b, sigma, l, rows=256):
     return out
 
 
+def lin_kernel(a, b, c):
+    """GP_regression.py:22-33"""
+    output_variance = 1
+    fun_mean = 0
+    dot_product = np.dot(a - c, b.T - c)
+    return fun_mean + output_variance * dot_product
+
+
+def per_kernel(a, b, parameters):
+    """GP_regression.py:36-50 (1-D inputs: np.tile at :48)"""
+    output_variance = 1
+    p, l = parameters
+    num_a = len(a)
+    num_b = len(b)
+    l2_norm = np.absolute(np.tile(a, (1, num_b)) - np.tile(b.T, (num_a, 1)))
+    return output_variance * np.exp(-2 * (np.sin(np.pi * l2_norm / p)) ** 2 / l ** 2)
+
+
+def prediction_other(X_train, X_test, y_train, kernel_choice, l, num_fun):
+    """GP_regression.py:109-156, 'lin' / 'per' branches (:129-136)"""
+    kern = lin_kernel if kernel_choice == 'lin' else per_kernel
+    s = NOISE_VAR
+    N, n = len(X_train), len(X_test)
+    K_train, K_s, K_ss = kern(X_train, X_train, l), kern(X_train, X_test, l), kern(X_test, X_test, l)
+    L = np.linalg.cholesky(K_train + s * np.eye(N))
+    m = np.linalg.solve(L, y_train)
+    alpha = np.linalg.solve(L.T, m)
+    mu_post = np.dot(K_s.T, alpha)
+    v = np.linalg.solve(L, K_s)
+    var_test = np.diag(K_ss) - np.sum(v ** 2, axis=0)
+    with np.errstate(invalid='ignore'):
+        stand_devi = np.sqrt(var_test)
+    L_ = np.linalg.cholesky(K_ss + POST_JITTER * np.eye(n) - np.dot(v.T, v))
+    f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(n, num_fun)))
+    return mu_post, stand_devi, f_post_fun
+
+
 _C_LIB = None
 
 

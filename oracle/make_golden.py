@@ -112,6 +112,23 @@ def edge_cases():
     np.savez_compressed(os.path.join(OUT, "edge_cases.npz"), **out)
 
 
+def other_kernels():
+    """the reference's lin_kernel / per_kernel and prediction() through them
+    (1-D inputs, as the reference uses them)."""
+    rng = np.random.default_rng(31)
+    X = rng.uniform(-5, 5, (200, 1)); Xs = np.linspace(-5, 5, 37).reshape(-1, 1)
+    y_lin = 0.7 * X[:, 0] - 0.3 + np.sqrt(5e-4) * rng.standard_normal(200)
+    y_per = np.sin(2 * np.pi * X[:, 0] / 3.0) + np.sqrt(5e-4) * rng.standard_normal(200)
+    out = dict(X=X, Xs=Xs, y_lin=y_lin, y_per=y_per, c=0.5, p=3.0, l=1.2)
+    out["K_lin"] = REF.lin_kernel(X[:40], Xs, 0.5)
+    out["K_per"] = REF.per_kernel(X[:40], Xs, (3.0, 1.2))
+    np.random.seed(41)
+    out["lin_mu"], out["lin_sd"], out["lin_fpost"] = REF.prediction(X, Xs, y_lin, 'lin', 0.5, 2)
+    np.random.seed(42)
+    out["per_mu"], out["per_sd"], out["per_fpost"] = REF.prediction(X, Xs, y_per, 'per', (3.0, 1.2), 2)
+    np.savez_compressed(os.path.join(OUT, "kernels_lin_per.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for sd_ in (0, 1, 2):
@@ -121,4 +138,5 @@ if __name__ == "__main__":
         dcase("d8_box5_N%d" % N, N, 8, 48, -5.0, 5.0, 4.0, 200 + N)
     dcase("d16_box1_N384", 384, 16, 40, -1.0, 1.0, 2.8, 316)
     edge_cases()
+    other_kernels()
     print("wrote", sorted(os.listdir(OUT)))

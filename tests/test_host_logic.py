@@ -40,10 +40,12 @@ def test_constants_are_the_reference_literals():
     assert T.NOISE_VAR == 0.0005 and T.BO_NOISE_VAR == 0.0001                    # tune...:302, :75
 
 
-def test_only_rbf_is_in_scope():
-    for k in ("lin", "per"):
-        with pytest.raises(NotImplementedError):
-            G.prediction(np.zeros((2, 1)), np.zeros((2, 1)), np.zeros(2), k, 1.0, 1)
+def test_unknown_kernel_choice_is_rejected_before_any_gpu_work():
+    class Dummy:            # no GPU here: the choice must be validated on the host
+        def set_kernel(self, *a):
+            pass
+    with pytest.raises(ValueError):
+        G.prediction(np.zeros((2, 1)), np.zeros((2, 1)), np.zeros(2), "matern", 1.0, 1, ctx=Dummy())
 
 
 def test_dataset_generator_follows_reference_rng_order(oracle):

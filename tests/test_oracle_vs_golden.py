@@ -96,3 +96,19 @@ def test_edge_cases(oracle):
     Kn = oracle.RBF_kernel(e["npd_X"], e["npd_X"], 1, float(e["npd_ell"]))
     with pytest.raises(np.linalg.LinAlgError):
         np.linalg.cholesky(Kn + float(e["npd_shift"]) * np.eye(len(Kn)))
+
+
+def test_linear_and_periodic_kernels(oracle):
+    """lin_kernel / per_kernel and prediction() through them."""
+    g = golden("kernels_lin_per")
+    X, Xs = g["X"], g["Xs"]
+    assert np.allclose(oracle.lin_kernel(X[:40], Xs, float(g["c"])), g["K_lin"], rtol=1e-15, atol=1e-15)
+    assert np.allclose(oracle.per_kernel(X[:40], Xs, (float(g["p"]), float(g["l"]))), g["K_per"], rtol=1e-15, atol=0)
+    np.random.seed(41)
+    mu, sd, fp = oracle.prediction_other(X, Xs, g["y_lin"], 'lin', float(g["c"]), 2)
+    assert np.allclose(mu, g["lin_mu"], atol=1e-9) and np.allclose(sd, g["lin_sd"], atol=1e-9)
+    assert np.allclose(fp, g["lin_fpost"], atol=FPOST_ATOL)
+    np.random.seed(42)
+    mu, sd, fp = oracle.prediction_other(X, Xs, g["y_per"], 'per', (float(g["p"]), float(g["l"])), 2)
+    assert np.allclose(mu, g["per_mu"], atol=1e-9) and np.allclose(sd, g["per_sd"], atol=1e-9)
+    assert np.allclose(fp, g["per_fpost"], atol=FPOST_ATOL)

@@ -172,6 +172,28 @@ def test_f_prior(ctx, oracle):
     assert np.allclose(fp, ref, atol=1e-9)
 
 
+def test_linear_and_periodic_kernels_vs_reference_golden(ctx):
+    """SURVEY.md section 8f row f4 through the drop-in: lin_kernel, per_kernel and prediction(..., 'lin' / 'per')."""
+    from gaussian_process_amd import GP_regression as G
+    g = golden("kernels_lin_per")
+    X, Xs, c, p, l = g["X"], g["Xs"], float(g["c"]), float(g["p"]), float(g["l"])
+    assert np.allclose(G.lin_kernel(X[:40], Xs, c), g["K_lin"], rtol=1e-15, atol=1e-15)
+    assert np.allclose(G.per_kernel(X[:40], Xs, (p, l)), g["K_per"], rtol=1e-14, atol=0)   # sin + exp, each < 2 ulp
+    np.random.seed(41)
+    mu, sd, fp = G.prediction(X, Xs, g["y_lin"], 'lin', c, 2)
+    assert np.allclose(mu, g["lin_mu"], atol=MU_ATOL) and np.allclose(sd, g["lin_sd"], atol=SD_ATOL)
+    assert np.allclose(fp, g["lin_fpost"], atol=FPOST_ATOL)
+    np.random.seed(42)
+    mu, sd, fp = G.prediction(X, Xs, g["y_per"], 'per', (p, l), 2)
+    assert np.allclose(mu, g["per_mu"], atol=MU_ATOL) and np.allclose(sd, g["per_sd"], atol=SD_ATOL)
+    assert np.allclose(fp, g["per_fpost"], atol=FPOST_ATOL)
+    # the context is back on the RBF kernel afterwards
+    g2 = golden("d8_box1_N64")
+    assert abs(ctx.fit(g2["X"], g2["y"], 1.0, 2.0, 5e-4) - g2["lml"]) <= LML_RTOL * abs(g2["lml"])
+    with pytest.raises(ValueError):
+        G.per_kernel(np.zeros((3, 2)), np.zeros((3, 2)), (1.0, 1.0))        # periodic kernel is 1-D only
+
+
 # ----------------------------------------------------------------------- edge cases
 def test_edge_cases_vs_reference_golden(ctx):
     e = golden("edge_cases")
