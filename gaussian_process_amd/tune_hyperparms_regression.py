@@ -40,3 +40,138 @@ def bayesian_opt(X_train, X_test, y_train, *, ctx=None):
     L_ = ctx.post_chol(1e-6)                               # :98
     f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(n, 1)))  # :99
     return mu_post, stand_devi, f_post_fun
+
+
+# ---------------------------------------------------------------------------------------
+# the Bayesian-optimisation loop around the batched LML -- a
+# Python-3 restatement of tune_hyperparms_regression.py:165-289 (acquisition functions) and
+# :316-395, :418-432 (candidate sampling, the loop, the driver).  Host code: the surrogate
+# GP has at most ~5 points; the accelerated part is compute_mar_likelihood_batch.
+# Plotting (plot_BO, the plt calls inside the acquisition functions) is out of scope.
+# The reference's Python-2 `random` stream cannot be reproduced by Python 3, so the outer
+# loop has no golden vectors ("parity unpinned"); its pieces are tested against their
+# formulas and the evaluated LMLs against the oracle.
+# ---------------------------------------------------------------------------------------
+import random  # noqa: E402
+
+from scipy.stats import norm  # noqa: E402
+
+from .GP_regression import prediction  # noqa: E402
+
+
+def _is_done(point, parms_done):
+    return float(np.ravel(point)[0]) in [float(v) for v in np.ravel(parms_done)]
+
+
+def PI(params, means, stand_devi, parms_done, y, n_iterations, k):
+    """Probability of improvement, reference :165-204.  Returns the next point (row of
+    params) or True when the early-stop criteria fire."""
+    s = 0.0005
+    stop_threshold = 0.001
+    f_max = np.max(y) + s
+    cumu_gaussian = norm.cdf((means - f_max) / stand_devi)
+    if cumu_gaussian.sum() <= stop_threshold or np.max(cumu_gaussian) <= stop_threshold:
+        return True                                              # :179-181
+    indices = np.where(cumu_gaussian == np.max(cumu_gaussian))[0]
+    next_point = params[indices[random.randint(0, len(indices) - 1)]]
+    if _is_done(next_point, parms_done):                        # :189-194: one redraw, then stop
+        next_point = params[indices[random.randint(0, len(indices) - 1)]]
+        if _is_done(next_point, parms_done):
+            return True
+    return next_point
+
+
+def UCB(parms_done, params, means, stand_devi, n_iterations, k):
+    """Upper confidence bound, reference :207-230 (kappa = 0.001)."""
+    kappa = 0.001
+    objective = means + kappa * stand_devi
+    next_point = params[np.where(objective == np.max(objective))[0][0]]
+    if np.ravel(parms_done)[-1] == np.ravel(next_point)[0]:
+        return True
+    return next_point
+
+
+def TS(parms_done, params, y, n_iterations, k, ctx=None):
+    """Thompson sampling, reference :233-250: one posterior sample of the surrogate."""
+    mu_post, stand_devi, f_post_fun = prediction(np.asarray(parms_done, dtype=np.float64).reshape(-1, 1),
+                                                 params, y, 'rbf', 1, 1, ctx=ctx)
+    return params[np.where(f_post_fun == np.max(f_post_fun))]
+
+
+def EI(params, means, stand_devi, parms_done, y, n_iterations, k):
+    """Expected improvement, reference :253-273."""
+    s = 0.0005
+    f_max = np.max(y) + s
+    z = (means - f_max) / stand_devi
+    EI_vector = (means - f_max) * norm.cdf(z) + stand_devi * norm.pdf(z)
+    return params[np.where(EI_vector == np.max(EI_vector))]
+
+
+def acquisition_fun(params, means, stand_devi, parms_done, y, n_iterations, k, ctx=None):
+    """Reference :275-289: all four are evaluated (they consume the RNG streams in this
+    order), the PI point is the one returned (:289)."""
+    next_point_PI = PI(params, means, stand_devi, parms_done, y, n_iterations, k)
+    UCB(parms_done, params, means, stand_devi, n_iterations, k)
+    TS(parms_done, params, y, n_iterations, k, ctx=ctx)
+    EI(params, means, stand_devi, parms_done, y, n_iterations, k)
+    return next_point_PI
+
+
+def overlap(a, b):
+    """Indices of the elements of a that occur in b and where they sit in b (both unique),
+    reference :316-328."""
+    ind_a = np.arange(len(a))[np.isin(a, b)]
+    ind_b = np.array([np.argwhere(b == a[x]) for x in ind_a]).flatten()
+    return ind_a, ind_b
+
+
+def random_gen_test_parms(n, parms_done):
+    """n sorted candidate lengthscales from linspace(0.01, 5, n + len(done) + 10) without the
+    ones already evaluated, shape (n, 1); reference :331-346."""
+    num_gen = n + len(parms_done) + 10
+    test_parms = np.linspace(0.01, 5, num_gen)
+    _, ind_sample = overlap(np.asarray(parms_done), test_parms)
+    test_parms = np.delete(test_parms, ind_sample.astype(int))
+    sampled = np.asarray(random.sample(list(test_parms), n))
+    return np.sort(sampled).reshape(-1, 1)
+
+
+def tune_hyperparms_second(X_train, X_test, y_train, num_fun, sigma, l, *, ctx=None, verbose=False,
+                           return_trace=False):
+    """The BO loop, reference :349-395: 3 iterations of {LML at every lengthscale tried so
+    far (one batched call here), surrogate GP, PI acquisition}; returns the best LML."""
+    ctx = ctx or default_context()
+    n = 100
+    n_iterations = 3
+    l = np.asarray(l, dtype=np.float64).reshape(-1)
+
+    def lml_of(ls):
+        triples = np.column_stack([ls, np.full(len(ls), float(sigma)), np.full(len(ls), NOISE_VAR)])
+        return compute_mar_likelihood_batch(X_train, y_train, triples, ctx=ctx)
+
+    k = 0
+    for k in range(n_iterations):
+        l_test = random_gen_test_parms(n, l)
+        log_marg_likelihood = lml_of(l)                                          # :368-369
+        mu_post, stand_devi, _ = bayesian_opt(l.reshape(-1, 1), l_test, log_marg_likelihood, ctx=ctx)   # :371
+        next_point = acquisition_fun(l_test, mu_post, stand_devi, l, log_marg_likelihood, n_iterations, k,
+                                     ctx=ctx)                                    # :373
+        if next_point is True:                                                   # :376-380
+            break
+        l = np.append(l, next_point)
+    log_marg_likelihood = lml_of(l)                                              # :384-386
+    best = int(np.argmax(log_marg_likelihood))
+    if verbose:
+        print("it takes %d iterations to get the optimal!" % (k + 1))
+        print("optimal lenghscalar is: %r" % l[best])
+        print("maximum likelihood is: %r" % np.max(log_marg_likelihood))
+    if return_trace:
+        return np.max(log_marg_likelihood), l, log_marg_likelihood
+    return np.max(log_marg_likelihood)
+
+
+def tune_hyperparms_BO(X_train, X_test, y_train, num_fun, *, ctx=None, verbose=False):
+    """Reference :418-432: sigma = 1, two random initial lengthscales in [0.02, 5)."""
+    sigma = 1
+    l = np.random.uniform(0.02, 5, 2)
+    return tune_hyperparms_second(X_train, X_test, y_train, num_fun, sigma, l, ctx=ctx, verbose=verbose)

@@ -55,3 +55,36 @@ def test_dataset_generator_follows_reference_rng_order(oracle):
     f2, X2, y2, Xs2 = oracle.dataset_generator(40, 9)
     assert np.array_equal(X, X2) and np.array_equal(y, y2) and np.array_equal(Xs, Xs2)
     assert X.shape == (40, 1) and y.shape == (40,) and Xs.shape == (9, 1)
+
+
+# ---- pieces of the Bayesian-optimisation loop (host code) -------------
+def test_acquisition_functions_follow_their_formulas():
+    from scipy.stats import norm
+    import random
+    params = np.linspace(0.01, 5, 50).reshape(-1, 1)
+    means = -(params[:, 0] - 2.0) ** 2
+    sd = 0.1 + 0.05 * params[:, 0]
+    done = np.array([0.5, 3.5])
+    y = np.array([-2.0, -2.5])
+    random.seed(0)
+    nxt = T.PI(params, means, sd, done, y, 3, 0)
+    cdf = norm.cdf((means - (y.max() + 0.0005)) / sd)
+    assert nxt.shape == (1,) and cdf[np.where(params[:, 0] == nxt[0])[0][0]] == cdf.max()
+    assert T.PI(params, np.full(50, -100.0), sd, done, y, 3, 0) is True           # nothing can improve: stop
+    assert T.UCB(done, params, means, sd, 3, 0)[0] == params[np.argmax(means + 0.001 * sd), 0]
+    assert T.UCB(np.array([0.5, params[np.argmax(means + 0.001 * sd), 0]]), params, means, sd, 3, 0) is True
+    z = (means - (y.max() + 0.0005)) / sd
+    ei = (means - (y.max() + 0.0005)) * norm.cdf(z) + sd * norm.pdf(z)
+    assert T.EI(params, means, sd, done, y, 3, 0)[0] == params[np.argmax(ei), 0]
+
+
+def test_candidate_sampling():
+    import random
+    random.seed(1)
+    done = np.array([0.01, 5.0, 1.234])
+    cand = T.random_gen_test_parms(100, done)
+    assert cand.shape == (100, 1) and np.all(np.diff(cand[:, 0]) > 0)
+    assert not np.isin(cand[:, 0], done).any()
+    assert np.all((cand >= 0.01) & (cand <= 5.0))
+    ia, ib = T.overlap(np.array([3.0, 7.0, 9.0]), np.array([9.0, 1.0, 3.0]))
+    assert ia.tolist() == [0, 2] and ib.tolist() == [2, 0]

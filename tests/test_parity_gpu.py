@@ -161,6 +161,25 @@ def test_bayesian_opt_surrogate(ctx, oracle):
     assert np.allclose(fp, fp_r, atol=FPOST_ATOL)
 
 
+def test_bayesian_optimisation_loop(ctx, oracle):
+    """SURVEY.md section 8f row f3 end to end (the reference's __main__ uses N = 3 training points): the value
+    returned is the best LML among the lengthscales the loop evaluated, each equal to the oracle's."""
+    import random
+    from gaussian_process_amd import GP_regression as G
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    np.random.seed(12)
+    random.seed(12)
+    f, X, y, Xs = G.dataset_generator(40, 100)
+    best, ls, lmls = T.tune_hyperparms_second(X, Xs, y, 10, 1, np.array([0.5, 3.5]), ctx=ctx, return_trace=True)
+    assert 2 <= len(ls) <= 5 and best == lmls.max()
+    for l, v in zip(ls, lmls):
+        want = oracle.compute_mar_likelihood(X, None, y, 1, l)
+        assert abs(v - want) <= LML_RTOL * abs(want)
+    np.random.seed(13)
+    random.seed(13)
+    assert np.isfinite(T.tune_hyperparms_BO(X, Xs, y, 10, ctx=ctx))
+
+
 def test_f_prior(ctx, oracle):
     from gaussian_process_amd import GP_regression as G
     Xt = np.linspace(-5, 5, 150).reshape(-1, 1)
