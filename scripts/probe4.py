@@ -4,8 +4,10 @@ sys.path.insert(0, ROOT)
 from gaussian_process_amd import GPContext
 ctx = GPContext(0)
 ctx.set_option("gemm_dma", 1)
-for waves in (4, 8):
+for waves in (8, 4):
     ctx.set_option("gemm_dma_waves", waves)
-    for (M, N, K, lower) in ((16384, 16384, 512, 0), (16384, 16384, 1024, 0), (32768, 32768, 1024, 1)):
-        tf, ms = ctx.probe_gemm(M, N, K, lower, 0, 5)
-        print("waves=%d dma gemm M=%d N=%d K=%d lower=%d: %.1f TF/s  %.3f ms" % (waves, M, N, K, lower, tf, ms), flush=True)
+    for K in (1024,):
+        for v in (0, 8, 9, 10, 11):
+            tf, ms = ctx.probe_gemm(16384, 16384, K, 0, 256 + v if v else 0, 5)
+            print("waves=%d K=%d variant=%2d: %.1f TF/s" % (waves, K, v, tf), flush=True)
+print(ctx.probe_mfma_f64_ex(1, 16, 4096), ctx.probe_mfma_f64_ex(2, 16, 4096), ctx.probe_mfma_f64_ex(2, 8, 4096))
