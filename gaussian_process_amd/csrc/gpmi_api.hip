@@ -447,6 +447,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "trsm_wave")) {
+        g_trsm_wave = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_dma_waves")) {
         if (value != 4 && value != 8) return fail_arg("gemm_dma_waves must be 4 or 8");
         g_gemm_dma_waves = (int)value;

@@ -45,6 +45,7 @@ double gemm_nt_flops(const GemmArgs& a);
 // Cholesky of one 64x64 diagonal block in place (lower), one wavefront.
 hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_offset,
                            int64_t* info_dev);
+extern int g_trsm_wave;   // tuning switch: wave-per-row (1) or lane-per-row (0) substitution kernel
 // X (m x 64) <- X * L^-T, L 64x64 lower; m multiple of 64.
 hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
                              int64_t m);

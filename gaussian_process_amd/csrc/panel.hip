@@ -28,9 +28,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // applies   A[r][c] -= c_r * c_c / p   (= l_r * l_c with l = c / sqrt(p));
 // the owners of column j+1 then publish their updated column for the next step.
 // 1/p is a v_rcp_f64 refined by two Newton steps, evaluated redundantly by all
-// threads (no second barrier for a broadcast).  The owners of column j scale
-// their copy by 1/sqrt(p) (v_rsq_f64 + coupled Newton steps, off the critical
-// path).  A non-positive (or NaN) pivot records col_offset + j in *info
+// threads (no second barrier for a broadcast).  The division by sqrt(p) is
+// deferred: the columns stay unscaled through the sweep and one final pass applies
+// 1/sqrt(p_c) (v_rsq_f64 + coupled Newton steps, 64 in parallel).  A non-positive (or NaN) pivot records col_offset + j in *info
 // (atomic min) and poisons the block with NaN.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void sqrt_and_rsqrt(double p, double& s, double& rinv) {
@@ -78,7 +78,6 @@ struct Potf2Step {
                     if (live) a[i][jj] = fma(-cr[i], w, a[i][jj]);
             }
         }
-        constexpr int JT = J >> 4;               // tile column of column J
         // owners of column J+1 publish it (rows above J+1 are never read)
         if constexpr (J < 63) {
             constexpr int NT = (J + 1) >> 4;
@@ -88,16 +87,9 @@ struct Potf2Step {
                 for (int i = NT; i < 4; ++i) nb[ty + 16 * i] = a[i][NT];
             }
         }
-        // owners of column J turn their unscaled copy into L (off the critical path)
-        if (tx == (J & 15)) {
-            double s, rinv;
-            sqrt_and_rsqrt(piv, s, rinv);
-#pragma unroll
-            for (int i = JT; i < 4; ++i) {
-                const int r = ty + 16 * i;
-                a[i][JT] = (r == J) ? s : a[i][JT] * rinv;
-            }
-        }
+        // the scaling by 1/sqrt(pivot) is deferred to the end of the kernel: its 15-deep
+        // dependent chain would otherwise sit in front of every barrier
+        if (threadIdx.x == 0) colbuf[128 + J] = piv;
         Potf2Step<J + 1>::run(a, tx, ty, col_offset, info, colbuf);
     }
 };
@@ -108,7 +100,7 @@ struct Potf2Step<64> {
 
 __global__ __launch_bounds__(256) void potf2_64_kernel(double* A, int64_t ld, int64_t col_offset,
                                                         int64_t* info) {
-    __shared__ __attribute__((aligned(16))) double colbuf[128];
+    __shared__ __attribute__((aligned(16))) double colbuf[128 + 64 + 128];   // columns | pivots | sqrt, 1/sqrt
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     double a[4][4];
 #pragma unroll
@@ -121,13 +113,23 @@ __global__ __launch_bounds__(256) void potf2_64_kernel(double* A, int64_t ld, in
         for (int i = 0; i < 4; ++i) colbuf[ty + 16 * i] = a[i][0];
     }
     Potf2Step<0>::run(a, tx, ty, col_offset, info, colbuf);
-    // store the lower triangle
+    // L[r][c] = (unscaled column entry) / sqrt(pivot_c), L[c][c] = sqrt(pivot_c): 64 parallel
+    // square roots, then one scaling pass
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double sq, rinv;
+        sqrt_and_rsqrt(colbuf[128 + threadIdx.x], sq, rinv);
+        colbuf[192 + threadIdx.x] = sq;
+        colbuf[256 + threadIdx.x] = rinv;
+    }
+    __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int jj = 0; jj <= i; ++jj) {
             const int r = ty + 16 * i, c = tx + 16 * jj;
-            if (c <= r) A[(int64_t)r * ld + c] = a[i][jj];
+            if (c < r) A[(int64_t)r * ld + c] = a[i][jj] * colbuf[256 + c];
+            else if (c == r) A[(int64_t)r * ld + c] = colbuf[192 + c];
         }
 }
 
@@ -144,6 +146,8 @@ hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_off
 // One lane per row of X; L^T sits in LDS (column c of L contiguous) and is
 // read as wave-wide 16-byte broadcasts.  One true division per column per block.
 // ---------------------------------------------------------------------------
+int g_trsm_wave = 1;   // 1: wave-per-row kernel, 0: lane-per-row kernel
+
 constexpr int TRSM_THREADS = 128;
 
 template <int C>
@@ -196,11 +200,66 @@ __global__ __launch_bounds__(TRSM_THREADS) void trsm_rlt64_kernel(const double* 
     for (int c = 0; c < 64; c += 2) *reinterpret_cast<d2*>(xr + c) = d2{x[c], x[c + 1]};
 }
 
+// ---------------------------------------------------------------------------
+// trsm_rlt64, wave-per-row form: lane c holds x[c] of a row; step C broadcasts
+// x[C] / L[C][C] with v_readlane and every lane c' > C applies
+// x[c'] -= x[C] * L[c'][C] (column C of L contiguous in LDS: conflict-free).
+// The dependent chain per row is 64 x (readlane, mul, fma) ~ 2k cycles instead of
+// 2016 FMAs per lane, rows are read and written as whole 512-byte lines, and a
+// wave interleaves TRSM_WR independent rows for latency cover.  This is what makes
+// the diagonal-block factorisation (few rows, launch after launch) short; for the
+// tall panels it costs about the same as the lane-per-row form.
+// ---------------------------------------------------------------------------
+constexpr int TRSM_WR = 4;      // rows per wave
+constexpr int TRSM_WT = 256;    // threads per block (4 waves -> 16 rows per block)
+
+__global__ __launch_bounds__(TRSM_WT) void trsm_rlt64_wave_kernel(const double* L, int64_t ldl, double* X,
+                                                                   int64_t ldx, int64_t m) {
+    __shared__ __attribute__((aligned(16))) double Lt[64 * 64];   // Lt[c][r] = L[r][c]
+    __shared__ double rd[64];
+    const int tid = threadIdx.x;
+    for (int p = tid; p < 64 * 64; p += TRSM_WT) {
+        const int r = p >> 6, c = p & 63;
+        Lt[c * 64 + r] = (c <= r) ? L[(int64_t)r * ldl + c] : 0.0;
+    }
+    if (tid < 64) rd[tid] = 1.0 / L[(int64_t)tid * ldl + tid];
+    __syncthreads();
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row0 = ((int64_t)blockIdx.x * (TRSM_WT / 64) + wave) * TRSM_WR;
+    if (row0 >= m) return;
+    double x[TRSM_WR];
+#pragma unroll
+    for (int i = 0; i < TRSM_WR; ++i) x[i] = (row0 + i < m) ? X[(row0 + i) * ldx + lane] : 0.0;
+#pragma unroll 4
+    for (int C = 0; C < 64; ++C) {
+        const double lc = Lt[C * 64 + lane];       // L[lane][C] (zero above the diagonal)
+        const double rdc = rd[C];
+#pragma unroll
+        for (int i = 0; i < TRSM_WR; ++i) {
+            const double xc = readlane_f64(x[i], C) * rdc;
+            x[i] = (lane == C) ? xc : fma(-xc, (lane > C) ? lc : 0.0, x[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TRSM_WR; ++i)
+        if (row0 + i < m) X[(row0 + i) * ldx + lane] = x[i];
+}
+
 hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
                              int64_t m) {
     if (m <= 0) return hipSuccess;
-    const int blocks = (int)((m + TRSM_THREADS - 1) / TRSM_THREADS);
-    hipLaunchKernelGGL(trsm_rlt64_kernel, dim3(blocks), dim3(TRSM_THREADS), 0, s, L, ldl, X, ldx, m);
+    // short panels (diagonal blocks, small problems, a rank's share): the wave-per-row kernel,
+    // whose latency is ~10x lower; tall panels run hidden under the trailing update, where the
+    // lane-per-row kernel disturbs the concurrent MFMA stream less
+    if (g_trsm_wave && m <= 16384) {
+        const int rows_per_block = (TRSM_WT / 64) * TRSM_WR;
+        const int blocks = (int)((m + rows_per_block - 1) / rows_per_block);
+        hipLaunchKernelGGL(trsm_rlt64_wave_kernel, dim3(blocks), dim3(TRSM_WT), 0, s, L, ldl, X, ldx, m);
+    } else {
+        const int blocks = (int)((m + TRSM_THREADS - 1) / TRSM_THREADS);
+        hipLaunchKernelGGL(trsm_rlt64_kernel, dim3(blocks), dim3(TRSM_THREADS), 0, s, L, ldl, X, ldx, m);
+    }
     return hipGetLastError();
 }
 
