@@ -72,10 +72,10 @@ __device__ __forceinline__ bool map_tile(const GemmDev& p, int& ti, int& tj) {
     return ti < p.Tm && tj < p.Tn;
 }
 
-template <int NI, bool DBG>
+template <int MI, int NI, bool DBG>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     const int dbg = DBG ? p.dbg : 0;   // ablation bits exist only in the probe instantiation
-    constexpr int TM = 128;
+    constexpr int TM = 32 * MI;               // 128 (MI = 4) or 64 (MI = 2: low-latency small tiles)
     constexpr int TN = 32 * NI;
     constexpr int A_SLOTS = KP * TM;          // 16-byte slots per stage
     constexpr int B_SLOTS = KP * TN;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = (wave >> 1) * 64;            // wave row offset in tile
+    const int wr = (wave >> 1) * (16 * MI);     // wave row offset in tile
     const int wc = (wave & 1) * (16 * NI);      // wave col offset in tile
     const int fr = lane & 15;
     const int fg = lane >> 4;
@@ -156,9 +156,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
         }
     };
 
-    d4 acc[4][NI];
+    d4 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) acc[i][j] = d4{0., 0., 0., 0.};
 
@@ -177,13 +177,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int kp = 4 * t + fg;
-            d2 fa[4], fb[NI];
+            d2 fa[MI], fb[NI];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = sa[kp * TM + ((wr + 16 * i + fr) ^ kp)];
+            for (int i = 0; i < MI; ++i) fa[i] = sa[kp * TM + ((wr + 16 * i + fr) ^ kp)];
 #pragma unroll
             for (int j = 0; j < NI; ++j) fb[j] = sb[kp * TN + ((wc + 16 * j + fr) ^ kp)];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
             // wait overlaps matrix work
             if (t == 1 && !(dbg & 3)) write_stage(buf ^ 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     if ((DBG && (dbg & 8))) {
         double t = 0.;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (t == 123.456) Cg[0] = t;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
         // store (a load behind a possibly aliasing store would otherwise wait for it:
         // 64 serial memory round trips per lane)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MI; ++i) {
             double cv[NI][4];
 #pragma unroll
             for (int j = 0; j < NI; ++j)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
@@ -241,21 +241,21 @@ int g_gemm_stagger = 0;    // s_sleep units (x 64 cycles); 0 disables (no measur
 int g_gemm_dbg = 0;
 int g_gemm_stagger_rule = 0;
 
-static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
+static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
     p.C = a.C; p.A = a.A; p.B = a.B;
     p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
-    p.Tm = (int)(a.M / 128);
+    p.Tm = (int)(a.M / TM);
     p.Tn = (int)(a.N / TN);
     p.nchunks = (int)(a.K / BK);
     p.mode = a.mode;
     p.lower = a.lower;
     p.diag_off = a.diag_off;
     p.row_ncols = a.row_ncols;
-    p.row_block_tiles = a.row_block_tiles > 0 ? a.row_block_tiles : 1;
+    p.row_block_tiles = (a.row_block_tiles > 0 ? a.row_block_tiles : 1) * (128 / TM);   // in TM-row bands
     // triangular super-tile enumeration only for square tiles on the diagonal
     // (and only when the region is not a tall skinny strip, where most
     // triangular super-tiles would be empty)
-    p.tri = (a.lower && TN == 128 && a.diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
+    p.tri = (a.lower && TM == TN && a.diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
     int S = 8;
     for (;; S >>= 1) {
         const int SM = (p.Tm + S - 1) / S, SN = (p.Tn + S - 1) / S;
@@ -275,6 +275,7 @@ static void plan(const GemmArgs& a, int TN, GemmDev& p, int& nblocks) {
 }
 
 int g_gemm_use_dma = 1;
+int g_gemm_small_tiles = 1;
 
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipSuccess;
@@ -284,21 +285,29 @@ hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
         return launch_gemm_nt_dma(s, a);
     GemmDev p;
     int nblocks;
-    if (a.N % 128 == 0) {
-        plan(a, 128, p, nblocks);
+    static bool attr = false;
+    if (!attr) {
+        constexpr int big = 2 * (KP * 128 + KP * 128) * 16;
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        attr = true;
+    }
+    // few tiles: one 128 x 128 tile keeps a CU busy for 1.8 us per 64 of K while the rest of the
+    // chip idles -- 64 x 64 tiles finish 4x sooner (panel-internal updates, diagonal blocks)
+    const int64_t tiles128 = (a.M / 128) * ((a.N + 127) / 128);
+    if (g_gemm_small_tiles && !g_gemm_dbg && tiles128 < 128) {
+        plan(a, 64, 64, p, nblocks);
+        constexpr size_t lds = 2 * (KP * 64 + KP * 64) * 16;
+        hipLaunchKernelGGL((gemm_nt_kernel<2, 2, false>), dim3(nblocks), dim3(256), lds, s, p);
+    } else if (a.N % 128 == 0) {
+        plan(a, 128, 128, p, nblocks);
         constexpr size_t lds = 2 * (KP * 128 + KP * 128) * 16;
-        static bool attr = false;
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr = true;
-        }
-        if (p.dbg) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), dim3(nblocks), dim3(256), lds, s, p);
-        else hipLaunchKernelGGL((gemm_nt_kernel<4, false>), dim3(nblocks), dim3(256), lds, s, p);
+        if (p.dbg) hipLaunchKernelGGL((gemm_nt_kernel<4, 4, true>), dim3(nblocks), dim3(256), lds, s, p);
+        else hipLaunchKernelGGL((gemm_nt_kernel<4, 4, false>), dim3(nblocks), dim3(256), lds, s, p);
     } else {
-        plan(a, 64, p, nblocks);
+        plan(a, 128, 64, p, nblocks);
         constexpr size_t lds = 2 * (KP * 128 + KP * 64) * 16;
-        hipLaunchKernelGGL((gemm_nt_kernel<2, false>), dim3(nblocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL((gemm_nt_kernel<4, 2, false>), dim3(nblocks), dim3(256), lds, s, p);
     }
     return hipGetLastError();
 }

@@ -447,6 +447,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_small_tiles")) {
+        g_gemm_small_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "trsm_wave")) {
         g_trsm_wave = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_dma_waves")) {

@@ -34,6 +34,7 @@ bool gemm_dma_eligible(const GemmArgs& a);
 hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
 extern unsigned long long* g_gemm_stamps;   // diagnostic stamp buffer (4096*4*4 u64) for gpmi_probe_gemm variant bit 16
 extern int g_gemm_dma_waves;  // 4 or 8 waves per workgroup in the LDS-DMA GEMM
+extern int g_gemm_small_tiles;   // 64 x 64 tiles for launches with few tiles
 extern int g_gemm_use_dma;   // 0: never, 1: for launches with >= 256 tiles
 extern int g_gemm_dbg;       // timing-only ablation bits for gpmi_probe_gemm (0 in production)
 extern int g_gemm_stagger_rule;
