@@ -222,7 +222,8 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     hipError_t e;
     hipStream_t sm = c->stream;
     const int64_t NB = c->block(ncols);
-    const bool la = c->lookahead && c->pstream && ncols > NB;
+    // below ~12k columns the two-stream choreography costs more than the panel it hides
+    const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
     hipStream_t sp_ = la ? c->pstream : sm;
     const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
     const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
@@ -352,7 +353,7 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
     const double* A = c->A.as<double>();
     const int64_t ld = c->ldA, Np = c->Np;
     const int64_t NB = c->block(Np);
-    const bool la = c->lookahead && c->pstream && Np > NB;
+    const bool la = c->lookahead && c->pstream && Np > NB && Np >= 12288;
     hipStream_t sp_ = la ? c->pstream : sm;
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
     auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
