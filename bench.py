@@ -181,13 +181,13 @@ def main():
             launches = stage.get("trail_launches", 0.0) / k
             ach = trail_flops / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01c_roofline_traffic.json")
             if os.path.exists(tpath) and N == 65536 and n == 4096:
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same
-                # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/collect_roofline.py)
+                # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/rocpd_extract.py traffic)
                 traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
             out["roofline"] = {
-                "kernel": "gemm_nt_dma_kernel<2> (Cholesky trailing update: 128x128 tile, 8 waves x 2x4 "
+                "kernel": "chol_trailing_update_dma_kernel (Cholesky trailing update: 128x128 tile, 8 waves x 2x4 "
                           "v_mfma_f64_16x16x4_f64, LDS-DMA staging)",
                 "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",

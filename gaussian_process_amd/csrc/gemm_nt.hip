@@ -277,12 +277,16 @@ static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
 int g_gemm_use_dma = 1;
 int g_gemm_small_tiles = 1;
 
+bool gemm_nt_routes_dma(const GemmArgs& a) {
+    // ablation bits >= 256 select the DMA kernel's ablations (low byte passed on)
+    return g_gemm_use_dma && (!g_gemm_dbg || g_gemm_dbg >= 256) && gemm_dma_eligible(a) &&
+           (a.M / 128) * (a.N / 128) >= 256;
+}
+
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipSuccess;
     if (a.M % 128 || a.N % 64 || a.K % BK) return hipErrorInvalidValue;
-    // ablation bits >= 256 select the DMA kernel's ablations (low byte passed on)
-    if (g_gemm_use_dma && (!g_gemm_dbg || g_gemm_dbg >= 256) && gemm_dma_eligible(a) && (a.M / 128) * (a.N / 128) >= 256)
-        return launch_gemm_nt_dma(s, a);
+    if (gemm_nt_routes_dma(a)) return launch_gemm_nt_dma(s, a);
     GemmDev p;
     int nblocks;
     static bool attr = false;

@@ -27,8 +27,10 @@ struct GemmArgs {
     // row blocks reach different distances to the right); device pointer or null
     const int32_t* row_ncols = nullptr;
     int row_block_tiles = 1;
+    int role = 0;   // 1: Cholesky trailing update (launched under its own kernel symbol)
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
+bool gemm_nt_routes_dma(const GemmArgs& a);   // true when launch_gemm_nt hands this launch to the LDS-DMA kernel
 // gemm_dma.hip: one-workgroup-per-CU LDS-DMA variant (mode 0, N % 128 == 0)
 bool gemm_dma_eligible(const GemmArgs& a);
 hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
