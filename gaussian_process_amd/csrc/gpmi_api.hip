@@ -65,6 +65,36 @@ struct DevBuf {
 
 struct TimedSpan { hipEvent_t a, b; int slot; };
 
+// Per-dimension bounding box of a point set (host side, at upload time).  Two boxes bound every
+// squared distance of a kernel-matrix launch, which lets the squared-exponential build drop its
+// per-wave exp domain test (RbfArgs::max_sq).  Non-finite inputs make the box invalid.
+struct Box {
+    std::vector<double> lo, hi;
+    bool valid = false;
+    void assign(const double* X, int64_t n, int64_t d) {
+        lo.assign((size_t)d, std::numeric_limits<double>::infinity());
+        hi.assign((size_t)d, -std::numeric_limits<double>::infinity());
+        bool finite = n > 0;
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t k = 0; k < d; ++k) {
+                const double v = X[i * d + k];
+                finite &= std::isfinite(v);
+                lo[(size_t)k] = std::min(lo[(size_t)k], v);
+                hi[(size_t)k] = std::max(hi[(size_t)k], v);
+            }
+        valid = finite;
+    }
+};
+double box_max_sq(const Box& a, const Box& b) {
+    if (!a.valid || !b.valid || a.lo.size() != b.lo.size()) return -1.0;
+    double s = 0.0;
+    for (size_t k = 0; k < a.lo.size(); ++k) {
+        const double w = std::max(a.hi[k] - b.lo[k], b.hi[k] - a.lo[k]);
+        s += w * w;
+    }
+    return std::isfinite(s) ? s : -1.0;
+}
+
 }  // namespace
 
 struct gpmi_ctx {
@@ -88,6 +118,7 @@ struct gpmi_ctx {
     int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
     bool have_test = false, have_v = false;
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
+    Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;
     // timers
     std::vector<hipEvent_t> ev_pool;
@@ -314,6 +345,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     r.nA = r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->Np; r.ncols = c->Np;
     set_kernel_args(c, r);
     r.diag_add = noise_var; r.symmetric = 1;
+    r.max_sq = box_max_sq(c->boxX, c->boxX);
     r.out = A; r.ld = c->ldA;
     HIP_TRY(launch_rbf(s, r));
     // the augmented rows: y then zeros
@@ -514,6 +546,13 @@ int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b,
                           ((int64_t)1 << 30) / (ld * 8) / TILE * TILE));
     int rc = GPMI_OK;
     hipError_t e;
+    double max_sq = -1.0;
+    if (kind == 0) {
+        Box ba, bb;
+        ba.assign(a, N, d);
+        bb.assign(b, M, d);
+        max_sq = box_max_sq(ba, bb);
+    }
     do {
         if ((e = da.ensure((size_t)N * d * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc a"); break; }
         if ((e = db.ensure((size_t)M * d * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc b"); break; }
@@ -529,6 +568,7 @@ int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b,
             r.nA = N; r.nB = M; r.d = d; r.row0 = r0; r.nrows = round_up(rows, TILE); r.ncols = Mp;
             r.coef = (kind == 0) ? -.5 * (1 / (ell * ell)) : 0.; r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
             r.kind = kind; r.kp0 = p0; r.kp1 = p1;
+            r.max_sq = max_sq;
             r.out = dout.as<double>(); r.ld = ld;
             if ((e = launch_rbf(s, r)) != hipSuccess) { rc = fail_runtime(e, "rbf kernel"); break; }
             if ((e = hipMemcpy2DAsync(out + r0 * M, (size_t)M * 8, dout.p, (size_t)ld * 8, (size_t)M * 8,
@@ -554,6 +594,7 @@ int gpmi_set_train(gpmi_ctx* c, const double* X, int64_t N, int64_t d, const dou
     HIP_TRY(hipMemcpyAsync(c->y.p, y, (size_t)N * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->N = N; c->d = d;
+    c->boxX.assign(X, N, d);
     c->have_train = true;
     return GPMI_OK;
 }
@@ -637,6 +678,7 @@ int gpmi_set_test(gpmi_ctx* c, const double* Xs, int64_t n) {
     HIP_TRY(hipMemcpyAsync(c->Xs.p, Xs, (size_t)n * c->d * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->hXs.assign(Xs, Xs + (size_t)n * c->d);
+    c->boxXs.assign(Xs, n, c->d);
     c->n = n;
     c->np_ = round_up(n, TILE);
     c->have_test = true;
@@ -662,6 +704,7 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     r.nA = c->n; r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->np_; r.ncols = c->Np;
     set_kernel_args(c, r);
     r.diag_add = 0.; r.symmetric = 0;
+    r.max_sq = box_max_sq(c->boxXs, c->boxX);
     r.out = V; r.ld = c->ldV;
     HIP_TRY(launch_rbf(s, r));
     c->span_end(sp);
@@ -724,6 +767,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     r.nA = r.nB = n; r.d = c->d; r.row0 = 0; r.nrows = np_; r.ncols = np_;
     set_kernel_args(c, r);
     r.diag_add = jitter; r.symmetric = 1;
+    r.max_sq = box_max_sq(c->boxXs, c->boxXs);
     r.out = P; r.ld = c->ldP;
     HIP_TRY(launch_rbf(s, r));
     GemmArgs g;  // P -= v^T v  (rows of V are the columns of v)

@@ -72,6 +72,9 @@ struct RbfArgs {
     // 2 periodic exp(-2 sin^2(pi |a-b| / p) / l^2), p = kp0, l = kp1, d == 1 (GP_regression.py:36-50)
     int kind = 0;
     double kp0 = 0., kp1 = 0.;
+    // upper bound of |a_i - b_j|^2 over the whole launch (from the inputs' bounding boxes), or < 0
+    // when unknown: lets the squared-exponential build skip its per-wave exp domain test
+    double max_sq = -1.0;
 };
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a);
 

@@ -41,6 +41,8 @@ struct RbfDev {
     int64_t ld;
     int kind;
     double kp0, kp1;
+    int nocheck;           // host-proved: every exp argument of this launch lies in [-700, 0]
+    int strip;             // rbf_regs_kernel: row tiles per block
 };
 
 #pragma clang fp contract(off)
@@ -67,9 +69,12 @@ __device__ __forceinline__ double sq_pw_small(FA a, FB b, int n) {
 }
 
 // exp(x) for the kernel's arguments (x <= 0): Cody-Waite reduction x = n*ln2 + r with the
-// round-to-nearest n taken from the low bits of x*log2(e) + 1.5*2^52, a degree-13 Taylor
-// polynomial in r (|r| <= ln2/2: truncation 4e-18), and 2^n applied by adding n to the
-// exponent field -- full-rate fp64 FMAs and two integer ops, no v_rndne/v_cvt/v_ldexp.
+// round-to-nearest n taken from the low bits of x*log2(e) + 1.5*2^52, a degree-11 minimax
+// polynomial in r (|r| <= ln2/2; 1 + r + r^2 P(r) fitted for relative error by
+// scripts/exp_poly_fit.py: 3.6e-18, 1.1e-17 with the coefficients rounded to double), and 2^n
+// applied by adding n to the exponent field -- full-rate fp64 FMAs and one integer op, no
+// v_rndne/v_cvt/v_ldexp.  The two leading coefficients are exactly 1, so exp(0) == 1 and the
+// diagonal of K is sigma^2 exactly, as in NumPy.
 // Valid while the result is a normal number; the caller falls back to the library exp
 // for the whole wave if any lane is outside [-700, 0] (or NaN).  Error < 1 ulp (checked
 // against NumPy at the 3-ulp parity tolerance of the K tests).
@@ -79,18 +84,16 @@ __device__ __forceinline__ double exp_neg_fast(double x) {
     const double n = t - MAGIC;
     double r = fma(-n, 6.93147180369123816490e-01, x);          // ln2_hi (low bits zero: exact)
     r = fma(-n, 1.90821492927058770002e-10, r);                 // ln2_lo
-    double q = 1.6059043836821613e-10;                          // 1/13!
-    q = fma(q, r, 2.08767569878681e-09);                        // 1/12!
-    q = fma(q, r, 2.505210838544172e-08);                       // 1/11!
-    q = fma(q, r, 2.755731922398589e-07);                       // 1/10!
-    q = fma(q, r, 2.7557319223985893e-06);                      // 1/9!
-    q = fma(q, r, 2.48015873015873e-05);                        // 1/8!
-    q = fma(q, r, 0.0001984126984126984);                       // 1/7!
-    q = fma(q, r, 0.001388888888888889);                        // 1/6!
-    q = fma(q, r, 0.008333333333333333);                        // 1/5!
-    q = fma(q, r, 0.041666666666666664);                        // 1/4!
-    q = fma(q, r, 0.16666666666666666);                         // 1/3!
-    q = fma(q, r, 0.5);
+    double q = 0x1.ad7f3c1cdbf13p-26;                           // c11
+    q = fma(q, r, 0x1.28ad9b87c947cp-22);                       // c10
+    q = fma(q, r, 0x1.71df25b4b9501p-19);                       // c9
+    q = fma(q, r, 0x1.a01999e260c97p-16);                       // c8
+    q = fma(q, r, 0x1.a01a012a0e822p-13);                       // c7
+    q = fma(q, r, 0x1.6c16c18438b14p-10);                       // c6
+    q = fma(q, r, 0x1.1111111127d10p-7);                        // c5
+    q = fma(q, r, 0x1.555555555083ep-5);                        // c4
+    q = fma(q, r, 0x1.55555555554f9p-3);                        // c3
+    q = fma(q, r, 0x1.000000000000ap-1);                        // c2
     q = fma(q, r, 1.0);
     q = fma(q, r, 1.0);
     const int ni = __double2loint(t);                           // n in the low word of t (two's complement)
@@ -101,7 +104,7 @@ __device__ __forceinline__ double exp_neg_fast(double x) {
 __device__ __forceinline__ void exp_pair(double x0, double x1, double& e0, double& e1) {
     // x = coef * (sum of squares) with coef < 0 is never positive; NaN fails the compare
     const bool ok = (x0 >= -700.0) & (x1 >= -700.0);
-    if (__all(ok)) {
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {                // compare mask straight into SGPRs
         e0 = exp_neg_fast(x0);
         e1 = exp_neg_fast(x1);
     } else {
@@ -237,27 +240,22 @@ __global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
 // Fast path for compile-time d (1..8, 16): no LDS, no barrier.  The two b columns of a
 // thread are 2*D contiguous doubles of X (coalesced 16-byte loads), the a row of a wave
 // is wave-uniform and comes through the scalar cache (s_load -> SGPR operands of the
-// VALU).  Interior tiles (all rows and columns inside the matrix, not on the diagonal)
-// skip every padding / diagonal test.
-template <int D, bool EDGE>
-__device__ __forceinline__ void rbf_tile_regs(const RbfDev& p, const double* __restrict__ Ap,
-                                              const double* __restrict__ Bp, double* __restrict__ outp,
-                                              int64_t grow0, int64_t gcol0, int ti) {
-    const int cp = threadIdx.x & 63;
-    const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t gc = gcol0 + 2 * cp;
-    double b0[D], b1[D];
-    if (!EDGE || gc + 1 < p.nB) {
+// VALU).  A block owns one 128-column tile and walks down a strip of row tiles with its b
+// columns resident in registers; blocks adjacent in blockIdx.x write adjacent 1-KiB
+// segments of the same rows.  Interior tiles (all rows and columns inside the matrix, not
+// on the diagonal) skip every padding / diagonal test.
+template <int D>
+__device__ __forceinline__ void rbf_load_cols(const RbfDev& p, const double* __restrict__ Bp, int64_t gc,
+                                              double (&b0)[D], double (&b1)[D]) {
+    if (gc + 1 < p.nB) {
         const double* bp = Bp + gc * D;
-        if constexpr ((2 * D) % 2 == 0) {
-            d2 t[D];
+        d2 t[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) t[k] = *reinterpret_cast<const d2*>(bp + 2 * k);
+        for (int k = 0; k < D; ++k) t[k] = *reinterpret_cast<const d2*>(bp + 2 * k);
 #pragma unroll
-            for (int k = 0; k < 2 * D; ++k) {
-                const double v = (k & 1) ? t[k >> 1].y : t[k >> 1].x;
-                if (k < D) b0[k] = v; else b1[k - D] = v;
-            }
+        for (int k = 0; k < 2 * D; ++k) {
+            const double v = (k & 1) ? t[k >> 1].y : t[k >> 1].x;
+            if (k < D) b0[k] = v; else b1[k - D] = v;
         }
     } else {
 #pragma unroll
@@ -266,37 +264,95 @@ __device__ __forceinline__ void rbf_tile_regs(const RbfDev& p, const double* __r
             b1[k] = 0.0;
         }
     }
-    double* out0 = outp + ((int64_t)ti * RT + 32 * rg) * p.ld + gc;
-#pragma unroll 2
-    for (int r = 0; r < 32; ++r) {
-        const int64_t gr = grow0 + 32 * rg + r;                 // wave-uniform
-        const double* ar = Ap + ((!EDGE || gr < p.nA) ? gr : 0) * D;
-        double av[D];
+    // pin the columns here so the wait for their loads sits before the row loops; a wait inside
+    // a loop would also wait for the inline-asm stores, which the compiler does not count
 #pragma unroll
-        for (int k = 0; k < D; ++k) av[k] = ar[k];               // scalar loads (uniform address)
-        const double s0 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b0[k]; });
-        const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
-        if constexpr (EDGE) {
+    for (int k = 0; k < D; ++k) {
+        asm volatile("" : "+v"(b0[k]));
+        asm volatile("" : "+v"(b1[k]));
+    }
+}
+
+template <int D, bool EDGE, bool CHECK = true, bool UNIT = false>
+__device__ __forceinline__ void rbf_tile_rows(const RbfDev& p, const double* __restrict__ Ap,
+                                              double* __restrict__ outp, int64_t grow0, int64_t gcol0, int ti,
+                                              const double (&b0)[D], const double (&b1)[D]) {
+    const int cp = threadIdx.x & 63;
+    const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if constexpr (EDGE) {
+        const int64_t gc = gcol0 + 2 * cp;
+        double* out0 = outp + ((int64_t)ti * RT + 32 * rg) * p.ld + gc;
+#pragma unroll 2
+        for (int r = 0; r < 32; ++r) {
+            const int64_t gr = grow0 + 32 * rg + r;                 // wave-uniform
+            const double* ar = Ap + ((gr < p.nA) ? gr : 0) * D;
+            double av[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) av[k] = ar[k];               // scalar loads (uniform address)
+            const double s0 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b0[k]; });
+            const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
             rbf_finish(p, gr, gc, s0, s1, out0 + (int64_t)r * p.ld);
-        } else {
+        }
+    } else {
+        // wave-uniform row base + constant 32-bit lane offset: the store takes the scalar-base form
+        double* urow = outp + ((int64_t)ti * RT + 32 * rg) * p.ld + gcol0;
+        const unsigned lane_off = 16u * (unsigned)cp;             // bytes
+        const double* arow = Ap + (grow0 + 32 * rg) * D;
+#pragma unroll 2
+        for (int r = 0; r < 32; ++r) {
+            const double* ar = arow + r * D;
+            double av[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) av[k] = ar[k];               // scalar loads (uniform address)
+            const double s0 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b0[k]; });
+            const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
             double e0, e1;
-            exp_pair(p.coef * s0, p.coef * s1, e0, e1);
-            *reinterpret_cast<d2*>(out0 + (int64_t)r * p.ld) = d2{p.sig2 * e0, p.sig2 * e1};
+            if constexpr (CHECK) {
+                exp_pair(p.coef * s0, p.coef * s1, e0, e1);
+            } else {
+                e0 = exp_neg_fast(p.coef * s0);
+                e1 = exp_neg_fast(p.coef * s1);
+            }
+            if constexpr (!UNIT) { e0 = p.sig2 * e0; e1 = p.sig2 * e1; }   // sigma^2 == 1: the product is exact
+            // global_store with SGPR base: the per-row address costs no vector instruction
+            const d2 ev = d2{e0, e1};
+            asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(lane_off), "v"(ev), "s"(urow + (int64_t)r * p.ld) : "memory");
         }
     }
 }
 
+// grid: x = column tile, y = strip of p.strip row tiles
 template <int D>
 __global__ __launch_bounds__(256) void rbf_regs_kernel(const double* __restrict__ Ap, const double* __restrict__ Bp,
                                                         double* __restrict__ outp, const RbfDev p) {
-    int ti, tj;
-    if (!rbf_map_tile(p, ti, tj)) return;
-    const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+    const int tj = blockIdx.x;
+    int ta = blockIdx.y * p.strip;
+    const int tb = min(ta + p.strip, p.Tm);
+    // symmetric build: only tiles that reach the diagonal or lie below it (row0 is a tile multiple)
+    if (p.symmetric) ta = max(ta, tj - (int)(p.row0 / RT));
+    if (ta >= tb) return;
     const int64_t gcol0 = (int64_t)tj * RT;
-    const bool inside = grow0 + RT <= p.nA && gcol0 + RT <= p.nB;
-    const bool on_diag = p.symmetric && gcol0 + RT > grow0;      // touches global row == col
-    if (inside && !on_diag) rbf_tile_regs<D, false>(p, Ap, Bp, outp, grow0, gcol0, ti);
-    else rbf_tile_regs<D, true>(p, Ap, Bp, outp, grow0, gcol0, ti);
+    double b0[D], b1[D];
+    rbf_load_cols<D>(p, Bp, gcol0 + 2 * (threadIdx.x & 63), b0, b1);
+    const bool unit = p.sig2 == 1.0;
+    for (int ti = ta; ti < tb; ++ti) {
+        const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+        const bool inside = grow0 + RT <= p.nA && gcol0 + RT <= p.nB;
+        const bool on_diag = p.symmetric && gcol0 + RT > grow0;      // touches global row == col
+        if (inside && !on_diag) {
+            // launch-uniform specialisations of the interior loop: no per-wave domain test when the
+            // host has bounded the arguments, no sigma^2 multiply when it is 1 (the reference's default)
+            if (p.nocheck) {
+                if (unit) rbf_tile_rows<D, false, false, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                else rbf_tile_rows<D, false, false, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+            } else {
+                if (unit) rbf_tile_rows<D, false, true, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                else rbf_tile_rows<D, false, true, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+            }
+        } else {
+            rbf_tile_rows<D, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+        }
+    }
 }
 
 // any d: operands straight from global memory (L2-resident), one column pair per thread
@@ -356,12 +412,15 @@ __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     if (a.nrows <= 0 || a.ncols <= 0) return hipSuccess;
     if (a.nrows % RT || a.ncols % RT || a.d <= 0) return hipErrorInvalidValue;
+    if (a.symmetric && a.row0 % RT) return hipErrorInvalidValue;
     RbfDev p;
     p.A = a.A; p.B = a.B; p.nA = a.nA; p.nB = a.nB; p.d = (int)a.d; p.row0 = a.row0;
     p.Tm = (int)(a.nrows / RT); p.Tn = (int)(a.ncols / RT);
     p.coef = a.coef; p.sig2 = a.sig2; p.diag_add = a.diag_add; p.symmetric = a.symmetric;
     p.out = a.out; p.ld = a.ld;
     p.kind = a.kind; p.kp0 = a.kp0; p.kp1 = a.kp1;
+    // coef <= 0 and max_sq bounds every squared distance of this launch (NaN / unknown fail the test)
+    p.nocheck = (a.max_sq >= 0.0 && a.coef <= 0.0 && a.coef * a.max_sq * 1.000001 >= -690.0) ? 1 : 0;
     if (a.kind < 0 || a.kind > 2 || (a.kind == 2 && a.d != 1)) return hipErrorInvalidValue;
     p.tri = (a.symmetric && a.row0 == 0 && p.Tm == p.Tn) ? 1 : 0;
     const int64_t nblk = p.tri ? (int64_t)p.Tm * (p.Tm + 1) / 2 : (int64_t)p.Tm * p.Tn;
@@ -371,7 +430,10 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
         hipLaunchKernelGGL(cov_other_kernel, grid, block, 0, s, p);
         return hipGetLastError();
     }
-#define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_regs_kernel<DD>, grid, block, 0, s, p.A, p.B, p.out, p); break
+    // big builds: 4 row tiles per block (b columns loaded once, 4x fewer block launches)
+    p.strip = (nblk >= 4096) ? 4 : 1;
+    const dim3 sgrid((unsigned)p.Tn, (unsigned)((p.Tm + p.strip - 1) / p.strip));
+#define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_regs_kernel<DD>, sgrid, block, 0, s, p.A, p.B, p.out, p); break
     if (a.d > LDS_MAXD) {
         hipLaunchKernelGGL(rbf_naive_kernel, grid, block, 0, s, p);
     } else {

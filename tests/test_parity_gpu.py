@@ -375,3 +375,26 @@ def test_cfg3_N65536_d8_properties(ctx, oracle):
 def test_d16_N8192_properties(ctx, oracle):
     X, y, Xs = oracle.synthetic_problem(8192, 16, 300)
     _check_solution_properties(ctx, X, y, Xs, 1.0, 2.8, 5e-4)
+
+
+@pytest.mark.parametrize("d", [1, 3, 8, 16])
+@pytest.mark.parametrize("sigma", [1.0, 1.7])
+@pytest.mark.parametrize("spread", [2.0, 60.0])
+def test_rbf_interior_tile_variants(ctx, oracle, d, sigma, spread):
+    """Sizes with interior 128x128 tiles, through every specialisation of the interior loop:
+    sigma == 1 (no sigma^2 multiply) or not; inputs whose bounding box proves every exp argument
+    inside [-700, 0] (no per-wave domain test) or, with spread 60, arguments far below -700
+    (per-wave fallback to the library exp: underflow to subnormals and to 0, as np.exp)."""
+    rng = np.random.default_rng(77 * d + int(spread))
+    a = rng.uniform(-spread, spread, (512, d))
+    b = rng.uniform(-spread, spread, (640, d))
+    ell = 1.1 * np.sqrt(d)
+    K = ctx.rbf(a, b, sigma, ell)
+    ref = oracle.RBF_kernel(a, b, sigma, ell)
+    if spread > 10:
+        assert ref.min() == 0.0 and (ref > 0).any()          # the case does reach underflow
+    assert np.allclose(K, ref, rtol=K_RTOL, atol=2e-323)     # atol: last bits of subnormal results
+    Ksym = ctx.rbf(a, a, sigma, ell)
+    assert np.array_equal(Ksym, Ksym.T)
+    assert np.array_equal(np.diag(Ksym), np.full(512, sigma ** 2))
+    assert np.allclose(Ksym, oracle.RBF_kernel(a, a, sigma, ell), rtol=K_RTOL, atol=2e-323)
