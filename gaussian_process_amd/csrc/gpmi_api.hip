@@ -488,6 +488,9 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         g_gemm_small_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "trsm_wave")) {
         g_trsm_wave = value ? 1 : 0;
+    } else if (!strcmp(name, "rbf_blocks")) {
+        if (value < 1 || value > (1 << 24)) return fail_arg("rbf_blocks must be in 1..2^24");
+        g_rbf_blocks = (int)value;
     } else if (!strcmp(name, "gemm_dma_waves")) {
         if (value != 4 && value != 8) return fail_arg("gemm_dma_waves must be 4 or 8");
         g_gemm_dma_waves = (int)value;
@@ -927,7 +930,7 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
 }
 
 int gpmi_probe_hbm_ex(gpmi_ctx* c, int64_t bytes, int mode, int blocks, double* gbps) {
-    if (!c || !gbps || bytes < 4096 || blocks < 1 || mode < 0 || mode > 5) return fail_arg("gpmi_probe_hbm_ex: bad argument");
+    if (!c || !gbps || bytes < 4096 || blocks < 1 || mode < 0 || mode > 6) return fail_arg("gpmi_probe_hbm_ex: bad argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->red.ensure(16 * 8));
     hipStream_t s = c->stream;

@@ -77,6 +77,7 @@ struct RbfArgs {
     double max_sq = -1.0;
 };
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a);
+extern int g_rbf_blocks;      // persistent blocks of the register-path K build (option "rbf_blocks")
 
 // ---- solve.hip -------------------------------------------------------------
 // dot[i] = sum_j V[i][j]*m[j], sq[i] = sum_j V[i][j]^2, j < ncols (fixed order)

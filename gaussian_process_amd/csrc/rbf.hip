@@ -42,7 +42,8 @@ struct RbfDev {
     int kind;
     double kp0, kp1;
     int nocheck;           // host-proved: every exp argument of this launch lies in [-700, 0]
-    int strip;             // rbf_regs_kernel: row tiles per block
+    int strip;             // rbf_regs_kernel: row tiles per work item
+    int nitems;            // rbf_regs_kernel: strips x column tiles
 };
 
 #pragma clang fp contract(off)
@@ -321,36 +322,42 @@ __device__ __forceinline__ void rbf_tile_rows(const RbfDev& p, const double* __r
     }
 }
 
-// grid: x = column tile, y = strip of p.strip row tiles
+// Work item = (strip of p.strip row tiles, column tile), column tile fastest.  Blocks are
+// persistent: block b takes items b, b + gridDim.x, ... (a bare store stream in this pattern
+// runs 10 % faster from persistent blocks than from one short block per item).
 template <int D>
 __global__ __launch_bounds__(256) void rbf_regs_kernel(const double* __restrict__ Ap, const double* __restrict__ Bp,
                                                         double* __restrict__ outp, const RbfDev p) {
-    const int tj = blockIdx.x;
-    int ta = blockIdx.y * p.strip;
-    const int tb = min(ta + p.strip, p.Tm);
-    // symmetric build: only tiles that reach the diagonal or lie below it (row0 is a tile multiple)
-    if (p.symmetric) ta = max(ta, tj - (int)(p.row0 / RT));
-    if (ta >= tb) return;
-    const int64_t gcol0 = (int64_t)tj * RT;
-    double b0[D], b1[D];
-    rbf_load_cols<D>(p, Bp, gcol0 + 2 * (threadIdx.x & 63), b0, b1);
     const bool unit = p.sig2 == 1.0;
-    for (int ti = ta; ti < tb; ++ti) {
-        const int64_t grow0 = p.row0 + (int64_t)ti * RT;
-        const bool inside = grow0 + RT <= p.nA && gcol0 + RT <= p.nB;
-        const bool on_diag = p.symmetric && gcol0 + RT > grow0;      // touches global row == col
-        if (inside && !on_diag) {
-            // launch-uniform specialisations of the interior loop: no per-wave domain test when the
-            // host has bounded the arguments, no sigma^2 multiply when it is 1 (the reference's default)
-            if (p.nocheck) {
-                if (unit) rbf_tile_rows<D, false, false, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
-                else rbf_tile_rows<D, false, false, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+    const int row_tile0 = (int)(p.row0 / RT);
+    for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
+        const int sy = item / p.Tn;
+        const int tj = item - sy * p.Tn;
+        int ta = sy * p.strip;
+        const int tb = min(ta + p.strip, p.Tm);
+        // symmetric build: only tiles that reach the diagonal or lie below it (row0 is a tile multiple)
+        if (p.symmetric) ta = max(ta, tj - row_tile0);
+        if (ta >= tb) continue;
+        const int64_t gcol0 = (int64_t)tj * RT;
+        double b0[D], b1[D];
+        rbf_load_cols<D>(p, Bp, gcol0 + 2 * (threadIdx.x & 63), b0, b1);
+        for (int ti = ta; ti < tb; ++ti) {
+            const int64_t grow0 = p.row0 + (int64_t)ti * RT;
+            const bool inside = grow0 + RT <= p.nA && gcol0 + RT <= p.nB;
+            const bool on_diag = p.symmetric && gcol0 + RT > grow0;      // touches global row == col
+            if (inside && !on_diag) {
+                // launch-uniform specialisations of the interior loop: no per-wave domain test when the
+                // host has bounded the arguments, no sigma^2 multiply when it is 1 (the reference's default)
+                if (p.nocheck) {
+                    if (unit) rbf_tile_rows<D, false, false, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                    else rbf_tile_rows<D, false, false, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                } else {
+                    if (unit) rbf_tile_rows<D, false, true, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                    else rbf_tile_rows<D, false, true, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                }
             } else {
-                if (unit) rbf_tile_rows<D, false, true, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
-                else rbf_tile_rows<D, false, true, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                rbf_tile_rows<D, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
             }
-        } else {
-            rbf_tile_rows<D, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
         }
     }
 }
@@ -409,6 +416,8 @@ __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
     }
 }
 
+int g_rbf_blocks = 16384;   // persistent blocks of the register-path build
+
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     if (a.nrows <= 0 || a.ncols <= 0) return hipSuccess;
     if (a.nrows % RT || a.ncols % RT || a.d <= 0) return hipErrorInvalidValue;
@@ -432,7 +441,8 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     }
     // big builds: 4 row tiles per block (b columns loaded once, 4x fewer block launches)
     p.strip = (nblk >= 4096) ? 4 : 1;
-    const dim3 sgrid((unsigned)p.Tn, (unsigned)((p.Tm + p.strip - 1) / p.strip));
+    p.nitems = p.Tn * ((p.Tm + p.strip - 1) / p.strip);
+    const dim3 sgrid((unsigned)std::min<int64_t>(p.nitems, g_rbf_blocks));
 #define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_regs_kernel<DD>, sgrid, block, 0, s, p.A, p.B, p.out, p); break
     if (a.d > LDS_MAXD) {
         hipLaunchKernelGGL(rbf_naive_kernel, grid, block, 0, s, p);

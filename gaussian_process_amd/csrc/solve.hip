@@ -265,6 +265,7 @@ hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks,
     return hipGetLastError();
 }
 
+// (modes 5 and 6 are described at their branches)
 // mode 0: grid-stride 16-byte stores; 1: the same, non-temporal; 2: each block streams one
 // contiguous span, 16-byte stores; 3: span + non-temporal; 4: read-only (16-byte loads)
 template <int MODE>
@@ -282,6 +283,25 @@ __global__ __launch_bounds__(256) void probe_write_kernel(double* buf, int64_t n
         for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
             if (MODE == 3) __builtin_nontemporal_store(val, p + i);
             else p[i] = val;
+        }
+    } else if (MODE == 6) {
+        // mode 5 restricted to the lower triangle of tiles (2-D grid-like order: column tile
+        // fastest, strips of 4 row tiles per block), n2 = 16-byte units of the FULL square
+        int64_t side = (int64_t)sqrt((double)(2 * n2));
+        side = side / 128 * 128;
+        const int64_t ld = side + 544;
+        const int T = (int)(side / 128);
+        const int S = (T + 3) / 4;
+        for (int t = blockIdx.x; t < T * S; t += gridDim.x) {
+            const int sy = t / T, tj = t - sy * T;
+            const int cp = threadIdx.x & 63, rg = threadIdx.x >> 6;
+            for (int ti = max(4 * sy, tj); ti < min(4 * sy + 4, T); ++ti) {
+                double* dst = buf + ((int64_t)ti * 128 + 32 * rg) * ld + (int64_t)tj * 128 + 2 * cp;
+                if (((int64_t)ti * 128 + 32 * rg + 31) * ld + (int64_t)tj * 128 + 2 * cp + 1 < 2 * n2) {
+#pragma unroll 4
+                    for (int r = 0; r < 32; ++r) *reinterpret_cast<d2*>(dst + (int64_t)r * ld) = val;
+                }
+            }
         }
     } else if (MODE == 5) {
         // the K-build store pattern without its arithmetic: 128 x 128 tiles of a square
@@ -318,6 +338,7 @@ hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles, int
         case 3: hipLaunchKernelGGL(probe_write_kernel<3>, g, b, 0, s, buf, n2, sink); break;
         case 4: hipLaunchKernelGGL(probe_write_kernel<4>, g, b, 0, s, buf, n2, sink); break;
         case 5: hipLaunchKernelGGL(probe_write_kernel<5>, g, b, 0, s, buf, n2, sink); break;
+        case 6: hipLaunchKernelGGL(probe_write_kernel<6>, g, b, 0, s, buf, n2, sink); break;
         default: hipLaunchKernelGGL(probe_write_kernel<0>, g, b, 0, s, buf, n2, sink); break;
     }
     return hipGetLastError();

@@ -11,6 +11,9 @@ d = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 reps = 20
 X, y, Xs = O.synthetic_problem(N, d, 16)
 ops = HipBlockOps(0)
+if len(sys.argv) > 3:
+    from gaussian_process_amd import GPContext
+    GPContext(0).set_option("rbf_blocks", int(sys.argv[3]))
 Xd = torch.from_numpy(X).cuda()
 A = torch.empty(N, N + 544, dtype=torch.float64, device="cuda")
 T = N // 128

@@ -1,9 +1,14 @@
+"""Bare HBM store patterns (gpmi_probe_hbm_ex): ceiling for the K build's write stream."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gaussian_process_amd import GPContext
 ctx = GPContext(0)
-for gb in (16,):
-    for mode in (5, 2, 0, 3):
-        for blocks in (1280, 2048, 16384, 131072):
-            print("bytes %d GiB mode %d blocks %6d: %.0f GB/s (nominal bytes)" % (gb, mode, blocks, ctx.probe_hbm_ex(gb << 30, mode, blocks)), flush=True)
+gb = 32
+T = 65536 // 128
+for mode in (6, 5, 2):
+    for blocks in (1280, 16384, 65536):
+        v = ctx.probe_hbm_ex(gb << 30, mode, blocks)
+        if mode == 6:
+            v *= 0.5 * (1 + 1.0 / T)       # only the lower tiles are written
+        print("buffer %d GiB mode %d blocks %6d: %.0f GB/s" % (gb, mode, blocks, v), flush=True)
