@@ -22,7 +22,7 @@ T_KBUILD, T_CHOL, T_CHOL_PANEL, T_CHOL_TRAIL, T_LML, T_KS, T_SOLVE_V, T_MEANVAR,
     T_ALPHA, T_POSTCHOL, T_TRAIL_LAUNCHES, T_TRAIL_FLOPS = range(12)
 T_COUNT = 16
 TIMER_NAMES = ["kbuild", "chol", "chol_panel", "chol_trail", "lml", "ks", "solve_v", "meanvar",
-               "alpha", "postchol", "trail_launches", "trail_flops"]
+               "alpha", "postchol", "trail_launches", "trail_flops", "grad"]
 
 _dp = C.POINTER(C.c_double)
 _i64 = C.c_int64
@@ -49,6 +49,8 @@ SIGNATURES = {
     "gpmi_predict_resident": [_vp, _dp, _dp, C.c_int],
     "gpmi_predict": [_vp, _dp, _i64, _dp, _dp, C.c_int],
     "gpmi_post_chol": [_vp, C.c_double, _dp, C.POINTER(_i64)],
+    "gpmi_lml_grad": [_vp, _dp, _dp],
+    "gpmi_grad_trace": [_vp, _dp, _dp, _i64, _i64, C.c_double, C.c_double, _dp, _dp, _dp, _dp],
     "gpmi_lml_batch": [_vp, _dp, _i64, _dp, C.POINTER(C.c_int)],
     "gpmi_get_timers": [_vp, _dp, C.c_int],
     "gpmi_sync": [_vp],

@@ -120,6 +120,8 @@ struct gpmi_ctx {
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;
+    DevBuf U, Kn, gpart;     // f2: L^-T, -(K+sI)^-1, per-tile partial sums of the gradient trace
+    double sigma = 1.0, ell = 1.0;   // hyper-parameters of the resident factorisation
     // timers
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
@@ -335,6 +337,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
                      GPMI_T_TRAIL_LAUNCHES, GPMI_T_TRAIL_FLOPS});
     c->sig2 = sigma * sigma;
     c->coef = -.5 * (1 / (ell * ell));      // GP_regression.py:19 evaluation order
+    c->sigma = sigma; c->ell = ell;
     double* A = c->A.as<double>();
     const int64_t big = std::numeric_limits<int64_t>::max();
     HIP_TRY(hipMemcpyAsync(c->info.p, &big, sizeof big, hipMemcpyHostToDevice, s));
@@ -383,7 +386,9 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
 // v^T = K_s^T L^-T: right-looking sweep over the block columns of L, with the
 // same lookahead split as the Cholesky (the triangular solve of block column
 // k+1 overlaps the update of the columns beyond it).
-hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
+// tri: V starts as the identity (m == Np), so at step k only rows < k + nb are non-zero in
+// block column k -- the sweep then costs Np^3/3 and leaves the upper triangular L^-T.
+hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri = false) {
     hipError_t e;
     hipStream_t sm = c->stream;
     const double* A = c->A.as<double>();
@@ -396,13 +401,13 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m) {
         GemmArgs g;   // V[:, c0..c0+ncol_upd) -= V[:, k..k+nb) * L[c0.., k..k+nb)^T
         g.C = V + c0; g.A = V + k; g.B = A + c0 * ld + k;
         g.ldc = g.lda = ldv; g.ldb = ld;
-        g.M = m; g.N = ncol_upd; g.K = nb;
+        g.M = tri ? std::min(m, k + nb) : m; g.N = ncol_upd; g.K = nb;
         g.mode = 0; g.lower = 0; g.diag_off = 0;
         return launch_gemm_nt(sm, g);
     };
     for (int64_t k = 0; k < Np; k += NB) {
         const int64_t nb = std::min<int64_t>(NB, Np - k);
-        if ((e = trsm_block(sp_, A + k * ld + k, ld, V + k, ldv, m, nb)) != hipSuccess) return e;
+        if ((e = trsm_block(sp_, A + k * ld + k, ld, V + k, ldv, tri ? std::min(m, k + nb) : m, nb)) != hipSuccess) return e;
         if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
         const int64_t r0 = k + nb;
         if (r0 >= Np) continue;
@@ -462,7 +467,8 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
     if (!c) return GPMI_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->X, &c->y, &c->A, &c->info, &c->red, &c->Xs, &c->V, &c->P, &c->vec, &c->dense})
+    for (DevBuf* b : {&c->X, &c->y, &c->A, &c->info, &c->red, &c->Xs, &c->V, &c->P, &c->vec, &c->dense,
+                       &c->U, &c->Kn, &c->gpart})
         b->release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -750,6 +756,124 @@ int gpmi_predict(gpmi_ctx* c, const double* Xs, int64_t n, double* mu, double* o
     int rc = gpmi_set_test(c, Xs, n);
     if (rc) return rc;
     return gpmi_predict_resident(c, mu, out2, want_sd);
+}
+
+// f2 -- gradient of the log marginal likelihood at the resident factorisation:
+// 0.5 * tr((alpha alpha^T - K_y^-1) dK/dtheta)  (tune_hyperparms_regression.py:43-57; the reference
+// builds K_y^-1 = inv(L.T) inv(L) at :144 and two N x N products).  Here: U = L^-T by the TRSM
+// sweep on the identity (N^3/3), -K_y^-1 = -U U^T by one MFMA GEMM per row block over the
+// non-zero column range (N^3/3), then one fused pass for the trace (grad.hip).
+int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
+    if (!c || !d_ell || !d_sigma) return fail_arg("gpmi_lml_grad: null argument");
+    if (!c->have_factor) return fail_arg("gpmi_lml_grad: no factorisation resident (call gpmi_factorize)");
+    if (c->kind != 0) return fail_arg("gpmi_lml_grad: squared-exponential kernel only (tune_hyperparms_regression.py:54)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t Np = c->Np, ld = c->ldA;
+    c->timers_reset({GPMI_T_GRAD});
+    HIP_TRY(c->U.ensure((size_t)Np * ld * 8));
+    HIP_TRY(c->Kn.ensure((size_t)Np * ld * 8));
+    HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
+    size_t sp = c->span_begin(GPMI_T_GRAD);
+    // alpha = L^-T m (a5)
+    double* alpha = c->vec.as<double>();
+    HIP_TRY(hipMemcpyAsync(alpha, c->A.as<double>() + Np * ld, (size_t)Np * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), ld, alpha, Np));
+    // U = I * L^-T
+    double* U = c->U.as<double>();
+    HIP_TRY(launch_fill_rows(s, U, ld, Np, Np, 0.0));
+    HIP_TRY(launch_set_identity_diag(s, U, ld, Np));
+    HIP_TRY(solve_sweep(c, U, ld, Np, true));
+    // Kn = -U U^T, lower tiles: row block i needs columns >= its first row only
+    double* Kn = c->Kn.as<double>();
+    HIP_TRY(launch_fill_rows(s, Kn, ld, Np, Np, 0.0));
+    const int64_t NB = c->block(Np);
+    for (int64_t r0 = 0; r0 < Np; r0 += NB) {
+        const int64_t nb = std::min<int64_t>(NB, Np - r0);
+        GemmArgs g;
+        g.C = Kn + r0 * ld; g.A = U + r0 * ld + r0; g.B = U + r0;
+        g.ldc = g.lda = g.ldb = ld;
+        g.M = nb; g.N = r0 + nb; g.K = Np - r0;
+        g.mode = 0; g.lower = 1; g.diag_off = r0;
+        HIP_TRY(launch_gemm_nt(s, g));
+    }
+    GradArgs a;
+    a.A = a.B = c->X.as<double>(); a.nA = a.nB = c->N; a.d = c->d;
+    a.row0 = 0; a.nrows = c->N;
+    a.alpha_r = a.alpha_c = alpha;
+    a.Kinv = Kn; a.ld = ld; a.kinv_sign = -1.0;
+    a.coef = c->coef; a.sig2 = c->sig2; a.two_sigma = 2 * c->sigma;
+    a.inv_l3 = 1.0 / (c->ell * c->ell * c->ell);
+    a.tri = 1;
+    const int64_t nblk = grad_trace_blocks(a);
+    HIP_TRY(c->gpart.ensure((size_t)nblk * 16));
+    a.partial = c->gpart.as<double>();
+    HIP_TRY(launch_grad_trace(s, a));
+    c->span_end(sp);
+    std::vector<double> part((size_t)nblk * 2);
+    HIP_TRY(hipMemcpyAsync(part.data(), a.partial, part.size() * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->timers_collect();
+    double sl = 0.0, ss = 0.0;
+    for (int64_t b = 0; b < nblk; ++b) { sl += part[2 * b]; ss += part[2 * b + 1]; }   // fixed order
+    *d_ell = .5 * sl;
+    *d_sigma = .5 * ss;
+    return GPMI_OK;
+}
+
+// The same trace from caller-supplied alpha and K_y^-1 (host, N x N row-major): the arguments the
+// reference's gradient_ascent(a, b, sigma, l, alpha, K_y) receives (tune_hyperparms_regression.py:31).
+int gpmi_grad_trace(gpmi_ctx* c, const double* a_in, const double* b_in, int64_t N, int64_t d, double sigma,
+                    double ell, const double* alpha_in, const double* Kinv_in, double* d_ell, double* d_sigma) {
+    if (!c || !a_in || !b_in || !alpha_in || !Kinv_in || !d_ell || !d_sigma) return fail_arg("gpmi_grad_trace: null argument");
+    if (N <= 0 || d <= 0) return fail_arg("gpmi_grad_trace: N and d must be positive");
+    if (!(ell != 0.0)) return fail_arg("gpmi_grad_trace: ell must be non-zero");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf da, db, dal, dk, dp;
+    const int64_t chunk = std::max<int64_t>(TILE, std::min<int64_t>(round_up(N, TILE), ((int64_t)1 << 30) / (N * 8) / TILE * TILE));
+    int rc = GPMI_OK;
+    hipError_t e = hipSuccess;
+    double sl = 0.0, ss = 0.0;
+    do {
+        if ((e = da.ensure((size_t)N * d * 8)) != hipSuccess || (e = db.ensure((size_t)N * d * 8)) != hipSuccess ||
+            (e = dal.ensure((size_t)N * 8)) != hipSuccess || (e = dk.ensure((size_t)chunk * N * 8)) != hipSuccess) {
+            rc = fail_runtime(e, "hipMalloc"); break;
+        }
+        if ((e = hipMemcpyAsync(da.p, a_in, (size_t)N * d * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(db.p, b_in, (size_t)N * d * 8, hipMemcpyHostToDevice, s)) != hipSuccess ||
+            (e = hipMemcpyAsync(dal.p, alpha_in, (size_t)N * 8, hipMemcpyHostToDevice, s)) != hipSuccess) {
+            rc = fail_runtime(e, "hipMemcpy H2D"); break;
+        }
+        for (int64_t r0 = 0; r0 < N && rc == GPMI_OK; r0 += chunk) {
+            const int64_t rows = std::min(chunk, N - r0);
+            if ((e = hipMemcpyAsync(dk.p, Kinv_in + r0 * N, (size_t)rows * N * 8, hipMemcpyHostToDevice, s)) != hipSuccess) {
+                rc = fail_runtime(e, "hipMemcpy H2D"); break;
+            }
+            GradArgs g;
+            g.A = da.as<double>(); g.B = db.as<double>(); g.nA = g.nB = N; g.d = d;
+            g.row0 = r0; g.nrows = rows;
+            g.alpha_r = g.alpha_c = dal.as<double>();
+            g.Kinv = dk.as<double>(); g.ld = N; g.kinv_sign = 1.0;
+            g.coef = -.5 * (1 / (ell * ell)); g.sig2 = sigma * sigma; g.two_sigma = 2 * sigma;
+            g.inv_l3 = 1.0 / (ell * ell * ell);
+            g.tri = 0;
+            const int64_t nblk = grad_trace_blocks(g);
+            if ((e = dp.ensure((size_t)nblk * 16)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
+            g.partial = dp.as<double>();
+            std::vector<double> part((size_t)nblk * 2);
+            if ((e = launch_grad_trace(s, g)) != hipSuccess ||
+                (e = hipMemcpyAsync(part.data(), g.partial, part.size() * 8, hipMemcpyDeviceToHost, s)) != hipSuccess ||
+                (e = hipStreamSynchronize(s)) != hipSuccess) {
+                rc = fail_runtime(e, "gradient trace"); break;
+            }
+            for (int64_t b = 0; b < nblk; ++b) { sl += part[2 * b]; ss += part[2 * b + 1]; }
+        }
+    } while (0);
+    (void)hipStreamSynchronize(s);
+    da.release(); db.release(); dal.release(); dk.release(); dp.release();
+    if (rc == GPMI_OK) { *d_ell = .5 * sl; *d_sigma = .5 * ss; }
+    return rc;
 }
 
 int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot) {

@@ -79,6 +79,26 @@ struct RbfArgs {
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a);
 extern int g_rbf_blocks;      // persistent blocks of the register-path K build (option "rbf_blocks")
 
+// ---- grad.hip --------------------------------------------------------------
+// sum_ij (alpha_i alpha_j - K_y^-1_ij) dK_ij/dtheta over a block of rows (tune_hyperparms_regression.py:54-57)
+struct GradArgs {
+    const double* A;          // row inputs  nA x d (device)
+    const double* B;          // col inputs  nB x d
+    int64_t nA, nB, d;
+    int64_t row0, nrows;      // rows row0 .. row0+nrows of the full matrix in this launch
+    const double* alpha_r;    // alpha indexed by global row
+    const double* alpha_c;    // alpha indexed by column
+    const double* Kinv;       // (row0 + r, c) at Kinv[r*ld + c]; holds kinv_sign * K_y^-1
+    int64_t ld;
+    double kinv_sign;
+    double coef, sig2, two_sigma, inv_l3;
+    int tri;                  // 1: symmetric case, lower tiles only (needs row0 == 0, nrows == nB)
+    double* partial;          // 2 doubles per block (grad_trace_blocks of them)
+};
+int64_t grad_trace_blocks(const GradArgs& a);
+hipError_t launch_grad_trace(hipStream_t s, const GradArgs& a);
+hipError_t launch_set_identity_diag(hipStream_t s, double* V, int64_t ld, int64_t n);
+
 // ---- solve.hip -------------------------------------------------------------
 // dot[i] = sum_j V[i][j]*m[j], sq[i] = sum_j V[i][j]^2, j < ncols (fixed order)
 hipError_t launch_row_dots(hipStream_t s, const double* V, int64_t ld, int64_t nrows,

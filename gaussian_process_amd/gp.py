@@ -179,6 +179,30 @@ class GPContext:
         check(st, bad.value)
         return out
 
+    # ---- f2: LML gradient ------------------------------------------------------------
+    def lml_grad(self):
+        """(dLML/dl, dLML/dsigma) at the resident factorisation:
+        .5*trace((alpha alpha^T - K_y^-1) dK/dtheta) (tune_hyperparms_regression.py:43-57)."""
+        dl, ds = C.c_double(), C.c_double()
+        check(self._lib.gpmi_lml_grad(self._h, C.byref(dl), C.byref(ds)))
+        return dl.value, ds.value
+
+    def grad_trace(self, a, b, sigma, l, alpha, K_y_inv):
+        """The same two traces from gradient_ascent's arguments (tune_hyperparms_regression.py:31)."""
+        a = as_f64(a, 2, "a")
+        b = as_f64(b, 2, "b")
+        N, d = a.shape
+        if b.shape != (N, d):
+            raise ValueError("a and b must both be (N, d): %s vs %s" % (a.shape, b.shape))
+        al = as_f64(np.asarray(alpha, dtype=np.float64).reshape(-1), 1, "alpha")
+        Ki = as_f64(K_y_inv, 2, "K_y")
+        if al.shape[0] != N or Ki.shape != (N, N):
+            raise ValueError("alpha must have N entries and K_y must be (N, N)")
+        dl, ds = C.c_double(), C.c_double()
+        check(self._lib.gpmi_grad_trace(self._h, ptr(a), ptr(b), N, d, scalar(sigma, "sigma"), scalar(l, "l"), ptr(al), ptr(Ki),
+                                        C.byref(dl), C.byref(ds)))
+        return dl.value, ds.value
+
     # ---- batched LML ----------------------------------------------------------------
     def lml_batch(self, triples):
         """triples: (T,3) = (l, sigma_f, noise_var) rows.  Returns (lml[T], status[T])."""

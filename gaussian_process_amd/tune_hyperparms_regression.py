@@ -1,7 +1,8 @@
 """Drop-in for the hot-path functions of the reference's
 tune_hyperparms_regression.py (which is Python-2 syntax and cannot be imported):
 `compute_mar_likelihood` (:292-313), the batch its callers loop over
-(:368-369, :385-386) and `bayesian_opt` (:67-101).
+(:368-369, :385-386), `bayesian_opt` (:67-101), the Bayesian-optimisation loop
+(:165-289, :316-395, :418-432) and the gradient-ascent tuner (:31-64, :104-162, :398-415).
 """
 from __future__ import annotations
 
@@ -175,3 +176,80 @@ def tune_hyperparms_BO(X_train, X_test, y_train, num_fun, *, ctx=None, verbose=F
     sigma = 1
     l = np.random.uniform(0.02, 5, 2)
     return tune_hyperparms_second(X_train, X_test, y_train, num_fun, sigma, l, ctx=ctx, verbose=verbose)
+
+
+# ---------------------------------------------------------------------------------------
+# the gradient-ascent tuner, reference :31-64, :104-162, :398-415.
+# The reference inverts L twice per iteration (:144) and multiplies two N x N matrices to read
+# off a trace (:55); here the inverse comes from the resident factor on the device and the
+# trace is one fused pass (gpmi_lml_grad), or -- for callers that hold alpha and K_y^-1
+# themselves, as gradient_ascent's signature has it -- gpmi_grad_trace.
+# ---------------------------------------------------------------------------------------
+GA_STEP_SIZE = 0.01      # :42
+GA_TOLERANCE = 0.001     # :117
+GA_MAX_ITER = 10000      # :121
+
+
+def gradient_ascent(a, b, sigma, l, alpha, K_y, *, ctx=None):
+    """One ascent step on the lengthscale, reference :31-64 (same arguments: alpha is
+    K_y^-1 y as a column, K_y the INVERSE of K + sI).  Returns (sigma, l): sigma unchanged,
+    as its update is commented out in the reference (:61)."""
+    ctx = ctx or default_context()
+    l_var, _ = ctx.grad_trace(a, b, sigma, l, alpha, K_y)        # :43-57
+    return sigma, l + GA_STEP_SIZE * l_var                       # :63
+
+
+def lml_and_gradient(X_train, y_train, sigma, l, *, noise_var=NOISE_VAR, ctx=None):
+    """LML (:141) and (dLML/dl, dLML/dsigma) (:54-57, :46-51) at (sigma, l) with everything
+    resident on the device: the body of the tuner's loop without its predictive part."""
+    ctx = ctx or default_context()
+    lml = ctx.fit(X_train, y_train, sigma, l, noise_var)
+    dl, ds = ctx.lml_grad()
+    return np.float64(lml), dl, ds
+
+
+def tune_hyperparms_first(X_train, X_test, y_train, num_fun, sigma, l, *, ctx=None, verbose=False,
+                          max_iter=GA_MAX_ITER, return_trace=False):
+    """Maximise the log marginal likelihood over the lengthscale by gradient ascent,
+    reference :104-162.  Same constants (s = 0.0005, step 0.01, tolerance 1e-3 on |dLML|,
+    at most 10000 iterations) and the same return values; the predictive mean / sd the
+    reference recomputes every iteration (:131-138) are evaluated once, for the iterate the
+    loop stops at -- which is what the reference returns."""
+    ctx = ctx or default_context()
+    ctx.set_train(X_train, y_train)
+    s = NOISE_VAR                                                # :115
+    log_marg_likelihood_old = 0                                  # :116
+    l_eval = l
+    it = 0
+    for i in range(max_iter):                                    # :121
+        it = i + 1
+        l_eval = l
+        log_marg_likelihood = np.float64(ctx.factorize(sigma, l, s))   # :123-129, :141
+        l_var, _ = ctx.lml_grad()                                # :144-145 (:43-57)
+        l = l + GA_STEP_SIZE * l_var                             # :63
+        error = np.sqrt(np.sum((log_marg_likelihood - log_marg_likelihood_old) ** 2))   # :147
+        log_marg_likelihood_old = log_marg_likelihood            # :148
+        if error <= GA_TOLERANCE:                                # :149
+            break
+    if verbose:
+        print("The hyperparameter tuning function has already converged after %d iterations!" % it)
+        print("optimal lenghscalar is: %r" % float(np.asarray(l).reshape(-1)[0]))
+        print("maximum log marginal likelihood is: %r" % log_marg_likelihood)
+    # the factor resident now belongs to l_eval, the lengthscale of the last loop body
+    mu_post, stand_devi = ctx.predict(X_test, want_sd=True)      # :131-138
+    N = mu_post.shape[0]
+    L_ = ctx.post_chol(1e-6)                                     # :159
+    f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(N, num_fun)))   # :160
+    if return_trace:
+        return mu_post, stand_devi, f_post_fun, log_marg_likelihood, l, it
+    return mu_post, stand_devi, f_post_fun, log_marg_likelihood
+
+
+def tune_hyperparms_gradient(X_train, X_test, y_train, num_fun, *, ctx=None, verbose=False):
+    """Reference :398-415: sigma = 1 and a random initial lengthscale in [0, 5); returns the
+    maximal log marginal likelihood (the reference's plotting calls are out of scope)."""
+    sigma = 1                                                    # :407
+    l = np.random.uniform(0, 5, 1)                               # :408
+    _, _, _, optimal_likelihood = tune_hyperparms_first(X_train, X_test, y_train, num_fun, sigma, l,
+                                                        ctx=ctx, verbose=verbose)   # :410
+    return optimal_likelihood

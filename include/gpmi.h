@@ -51,6 +51,7 @@ enum {
     GPMI_T_POSTCHOL = 9,  /* f1: v^T v, K** + jitter*I - v^T v, its Cholesky */
     GPMI_T_TRAIL_LAUNCHES = 10, /* number of trailing-update launches in last fit */
     GPMI_T_TRAIL_FLOPS = 11,    /* algorithmic flops of those launches (2*M*N*K over computed tiles) */
+    GPMI_T_GRAD = 12,     /* f2: L^-T, K_y^-1 and the fused gradient trace */
     GPMI_T_COUNT = 16
 };
 
@@ -127,6 +128,20 @@ int gpmi_predict(gpmi_ctx* ctx, const double* Xs, int64_t n, double* mu, double*
  * for the test set of the last predict; L_out: n x n row-major, zeros above the
  * diagonal.   */
 int gpmi_post_chol(gpmi_ctx* ctx, double jitter, double* L_out, int64_t* bad_pivot);
+
+/* Gradient of the log marginal likelihood at the resident factorisation:
+ *   d_ell   = .5 * trace((alpha alpha^T - K_y^-1) @ l_grad),     l_grad     = sigma^2 exp(-.5 sqdist/l^2) sqdist/l^3
+ *                                                     tune_hyperparms_regression.py:54-57
+ *   d_sigma = .5 * trace((alpha alpha^T - K_y^-1) @ sigma_grad), sigma_grad = 2 sigma exp(-.5 sqdist/l^2)
+ *                                                     tune_hyperparms_regression.py:46-51 (commented out there)
+ * with K_y^-1 = inv(L.T) @ inv(L) (:144) formed on the device from the resident L.
+ * Squared-exponential kernel only. */
+int gpmi_lml_grad(gpmi_ctx* ctx, double* d_ell, double* d_sigma);
+/* The same two traces from the arguments gradient_ascent(a, b, sigma, l, alpha, K_y) receives
+ * (tune_hyperparms_regression.py:31): a, b: N x d; alpha: N; K_y_inv: N x N row-major (host).
+ * One fused N^2 pass instead of the reference's two N x N products (:55). */
+int gpmi_grad_trace(gpmi_ctx* ctx, const double* a, const double* b, int64_t N, int64_t d, double sigma,
+                    double ell, const double* alpha, const double* K_y_inv, double* d_ell, double* d_sigma);
 
 /* compute_mar_likelihood for T hyper-parameter triples on one training set
  *                    tune_hyperparms_regression.py:292-313 called in the loops at :368-369,:385-386

@@ -197,6 +197,77 @@ def bayesian_opt(X_train, X_test, y_train):
 
 
 # ---------------------------------------------------------------------------
+# gradient-ascent tuner
+# ---------------------------------------------------------------------------
+GA_STEP_SIZE = 0.01          # tune_hyperparms_regression.py:42
+GA_TOLERANCE = 0.001         # tune_hyperparms_regression.py:117
+GA_MAX_ITER = 10000          # tune_hyperparms_regression.py:121
+
+
+def lml_gradient_terms(a, b, sigma, l, alpha, K_y):
+    """tune_hyperparms_regression.py:43-57: (l_var, sigma_var).  l_var is the live code
+    (:54-57); sigma_var is the commented-out twin (:46-51), restated with the same calls.
+    alpha: (N, 1); K_y: the inverse of K + s I (:144)."""
+    sqdist = ((a[:, :, None] - b[:, :, None].T) ** 2).sum(1)                  # :43
+    sigma_grad = 2 * sigma * np.exp(-.5 * sqdist / (l ** 2))                 # :48
+    sigma_matrix = np.dot(np.dot(alpha, alpha.T) - K_y, sigma_grad)          # :49
+    sigma_var = .5 * np.diagonal(sigma_matrix).sum()                         # :50-51
+    l_grad = sigma ** 2 * np.exp(-.5 * sqdist / (l ** 2)) * (sqdist / l ** 3)  # :54
+    l_matrix = np.dot(np.dot(alpha, alpha.T) - K_y, l_grad)                  # :55
+    l_var = .5 * np.diagonal(l_matrix).sum()                                 # :56-57
+    return l_var, sigma_var
+
+
+def gradient_ascent(a, b, sigma, l, alpha, K_y):
+    """tune_hyperparms_regression.py:31-64: one ascent step on l (sigma is returned unchanged,
+    its update is commented out at :61)."""
+    l_var, _ = lml_gradient_terms(a, b, sigma, l, alpha, K_y)
+    return sigma, l + GA_STEP_SIZE * l_var                                   # :63
+
+
+def lml_and_gradient(X_train, y_train, sigma, l, s=NOISE_VAR):
+    """One iteration of tune_hyperparms_first's loop body without the predictive part
+    (tune_hyperparms_regression.py:123-145): LML, (l_var, sigma_var), alpha, K_y_inv."""
+    n = len(X_train)
+    K_train = RBF_kernel(X_train, X_train, sigma, l)                         # :123
+    L = np.linalg.cholesky(K_train + s * np.eye(n))                          # :127
+    m = np.linalg.solve(L, y_train)                                          # :128
+    alpha = np.linalg.solve(L.T, m)                                          # :129
+    lml = (-.5 * np.dot(y_train.T, alpha) - np.log(np.diagonal(L)).sum(0)
+           - n / 2.0 * np.log(2 * np.pi))                                    # :141
+    K_y_inv = np.dot(np.linalg.inv(L.T), np.linalg.inv(L))                   # :144
+    l_var, sigma_var = lml_gradient_terms(X_train, X_train, sigma, l, alpha.reshape(-1, 1), K_y_inv)
+    return lml, l_var, sigma_var, alpha, K_y_inv
+
+
+def tune_hyperparms_first(X_train, X_test, y_train, num_fun, sigma, l, max_iter=GA_MAX_ITER):
+    """tune_hyperparms_regression.py:104-162 (prints and the plt.axis call dropped).  Returns
+    (mu_post, stand_devi, f_post_fun, optimal_likelihood) and, as extras for the tests,
+    the final l and the iteration count."""
+    s = NOISE_VAR                                                            # :115
+    log_marg_likelihood_old = 0                                              # :116
+    N = len(X_test)
+    it = 0
+    for i in range(max_iter):                                                # :121
+        it = i + 1
+        p = posterior(X_train, X_test, y_train, sigma, l, s)                 # :123-138
+        with np.errstate(invalid='ignore'):
+            stand_devi = np.sqrt(p['var'])
+        n = len(X_train)
+        log_marg_likelihood = (-.5 * np.dot(y_train.T, p['alpha']) - np.log(np.diagonal(p['L'])).sum(0)
+                               - n / 2.0 * np.log(2 * np.pi))                # :141
+        K_y_inv = np.dot(np.linalg.inv(p['L'].T), np.linalg.inv(p['L']))     # :144
+        sigma, l = gradient_ascent(X_train, X_train, sigma, l, p['alpha'].reshape(-1, 1), K_y_inv)  # :145
+        error = np.sqrt(np.sum((log_marg_likelihood - log_marg_likelihood_old) ** 2))  # :147
+        log_marg_likelihood_old = log_marg_likelihood                        # :148
+        if error <= GA_TOLERANCE:                                            # :149
+            break
+    L_ = np.linalg.cholesky(p['K_ss'] + POST_JITTER * np.eye(N) - np.dot(p['v'].T, p['v']))   # :159
+    f_post_fun = p['mu'].reshape(-1, 1) + np.dot(L_, np.random.normal(size=(N, num_fun)))     # :160
+    return p['mu'], stand_devi, f_post_fun, log_marg_likelihood, l, it
+
+
+# ---------------------------------------------------------------------------
 # Memory-feasible restatement (BASELINE.md section 3): identical K arithmetic, but true
 # triangular solves instead of LU on a triangular matrix.  Used as the CPU
 # baseline at sizes where the (N,d,N) broadcast does not fit, and as the

@@ -129,6 +129,39 @@ def other_kernels():
     np.savez_compressed(os.path.join(OUT, "kernels_lin_per.npz"), **out)
 
 
+def grad_cases():
+    """the gradient-ascent terms.  tune_hyperparms_regression.py is Python-2
+    syntax (not importable), so its lines :123-129, :141, :144 and :43-57 are issued here with
+    the IMPORTED RBF_kernel and the same NumPy calls (the sigma term is the commented-out
+    code at :46-51)."""
+    out = {}
+    for tag, N, d, lo, hi, sigma, l in (("a", 96, 1, -5.0, 5.0, 1.0, 1.0), ("b", 200, 3, -2.0, 2.0, 1.3, 0.8),
+                                        ("c", 384, 8, -1.0, 1.0, 1.0, 2.0)):
+        rng = np.random.default_rng(500 + N)
+        X = rng.uniform(lo, hi, (N, d))
+        y = np.sin(0.9 * X.sum(1)) + np.sqrt(5e-4) * rng.standard_normal(N)
+        s = 0.0005
+        K_train = REF.RBF_kernel(X, X, sigma, l)                                    # :123
+        L = np.linalg.cholesky(K_train + s * np.eye(N))                             # :127
+        m = np.linalg.solve(L, y)                                                   # :128
+        alpha = np.linalg.solve(L.T, m)                                             # :129
+        lml = -.5 * np.dot(y.T, alpha) - np.log(np.diagonal(L)).sum(0) - N / 2.0 * np.log(2 * np.pi)   # :141
+        K_y = np.dot(np.linalg.inv(L.T), np.linalg.inv(L))                          # :144
+        al = alpha.reshape(-1, 1)
+        a = b = X
+        sqdist = ((a[:, :, None] - b[:, :, None].T) ** 2).sum(1)                    # :43
+        sigma_grad = 2 * sigma * np.exp(-.5 * sqdist / (l ** 2))                    # :48
+        sigma_var = .5 * np.diagonal(np.dot(np.dot(al, al.T) - K_y, sigma_grad)).sum()   # :49-51
+        l_grad = sigma ** 2 * np.exp(-.5 * sqdist / (l ** 2)) * (sqdist / l ** 3)   # :54
+        l_var = .5 * np.diagonal(np.dot(np.dot(al, al.T) - K_y, l_grad)).sum()      # :55-57
+        out.update({tag + "_X": X, tag + "_y": y, tag + "_sigma": sigma, tag + "_l": l, tag + "_lml": lml,
+                    tag + "_alpha": alpha, tag + "_l_var": l_var, tag + "_sigma_var": sigma_var,
+                    tag + "_l_next": l + 0.01 * l_var})                              # :42, :63
+        if N <= 200:
+            out[tag + "_Kyinv"] = K_y          # the larger inverse is recomputed by the tests (fixture size)
+    np.savez_compressed(os.path.join(OUT, "kernels_grad.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for sd_ in (0, 1, 2):
@@ -139,4 +172,5 @@ if __name__ == "__main__":
     dcase("d16_box1_N384", 384, 16, 40, -1.0, 1.0, 2.8, 316)
     edge_cases()
     other_kernels()
+    grad_cases()
     print("wrote", sorted(os.listdir(OUT)))

@@ -112,3 +112,40 @@ def test_linear_and_periodic_kernels(oracle):
     mu, sd, fp = oracle.prediction_other(X, Xs, g["y_per"], 'per', (float(g["p"]), float(g["l"])), 2)
     assert np.allclose(mu, g["per_mu"], atol=1e-9) and np.allclose(sd, g["per_sd"], atol=1e-9)
     assert np.allclose(fp, g["per_fpost"], atol=FPOST_ATOL)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gradient_ascent_terms(oracle, tag):
+    """LML, the two gradient traces and one ascent step against the
+    vectors produced with the imported RBF_kernel and the reference's statements
+    (tune_hyperparms_regression.py:123-145, :43-63)."""
+    g = golden("kernels_grad")
+    X, y = g[tag + "_X"], g[tag + "_y"]
+    sigma, l = float(g[tag + "_sigma"]), float(g[tag + "_l"])
+    lml, l_var, sigma_var, alpha, K_y = oracle.lml_and_gradient(X, y, sigma, l)
+    assert abs(lml - float(g[tag + "_lml"])) <= 1e-12 * abs(float(g[tag + "_lml"]))
+    assert np.allclose(alpha, g[tag + "_alpha"], rtol=0, atol=1e-9 * np.abs(alpha).max())
+    # the traces cancel two terms of size ~|tr(K_y^-1 dK)|; same LAPACK calls, so nearly bitwise
+    assert abs(l_var - float(g[tag + "_l_var"])) <= 1e-9 * max(1.0, abs(float(g[tag + "_l_var"])))
+    assert abs(sigma_var - float(g[tag + "_sigma_var"])) <= 1e-9 * max(1.0, abs(float(g[tag + "_sigma_var"])))
+    _, l_next = oracle.gradient_ascent(X, X, sigma, l, alpha.reshape(-1, 1), K_y)
+    assert abs(l_next - float(g[tag + "_l_next"])) <= 1e-11 * max(1.0, abs(l_next))
+    # finite-difference check of the restated formulas themselves
+    h = 1e-5
+    fd_l = (oracle.compute_mar_likelihood(X, None, y, sigma, l + h) -
+            oracle.compute_mar_likelihood(X, None, y, sigma, l - h)) / (2 * h)
+    fd_s = (oracle.compute_mar_likelihood(X, None, y, sigma + h, l) -
+            oracle.compute_mar_likelihood(X, None, y, sigma - h, l)) / (2 * h)
+    assert abs(fd_l - l_var) <= 1e-5 * max(1.0, abs(l_var))
+    assert abs(fd_s - sigma_var) <= 1e-5 * max(1.0, abs(sigma_var))
+
+
+def test_gradient_ascent_loop_converges(oracle):
+    """tune_hyperparms_first (:104-162) on the reference's own data shape: the loop stops on
+    |dLML| <= 1e-3 and lands on a stationary lengthscale."""
+    np.random.seed(3)
+    f, X, y, Xs = oracle.dataset_generator(40, 25)
+    mu, sd, fp, lml, l, it = oracle.tune_hyperparms_first(X, Xs, y, 2, 1, np.array([1.5]), max_iter=400)
+    assert it < 400 and mu.shape == (25,) and sd.shape == (25,) and fp.shape == (25, 2)
+    _, l_var, _, _, _ = oracle.lml_and_gradient(X, y, 1, float(l[0]))
+    assert abs(0.01 * l_var) < 1e-2          # the step that would follow is small

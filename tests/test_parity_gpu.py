@@ -398,3 +398,115 @@ def test_rbf_interior_tile_variants(ctx, oracle, d, sigma, spread):
     assert np.array_equal(Ksym, Ksym.T)
     assert np.array_equal(np.diag(Ksym), np.full(512, sigma ** 2))
     assert np.allclose(Ksym, oracle.RBF_kernel(a, a, sigma, ell), rtol=K_RTOL, atol=2e-323)
+
+
+# ----------------------------------------------------------------------------- f2: LML gradient
+GRAD_RTOL = 1e-8      # relative to |.5 a^T dK a| + |.5 tr(K_y^-1 dK)|, the two terms the trace cancels
+
+
+def _grad_scale(oracle, X, sigma, l, alpha, K_y):
+    sq = ((X[:, :, None] - X[:, :, None].T) ** 2).sum(1)
+    e = np.exp(-.5 * sq / l ** 2)
+    Dl, Ds = sigma ** 2 * e * sq / l ** 3, 2 * sigma * e
+    return (.5 * abs(alpha @ Dl @ alpha) + .5 * abs(np.sum(K_y * Dl)),
+            .5 * abs(alpha @ Ds @ alpha) + .5 * abs(np.sum(K_y * Ds)))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_lml_grad_vs_reference_golden(ctx, oracle, tag):
+    g = golden("kernels_grad")
+    X, y = g[tag + "_X"], g[tag + "_y"]
+    sigma, l = float(g[tag + "_sigma"]), float(g[tag + "_l"])
+    lml = ctx.fit(X, y, sigma, l, 5e-4)
+    assert abs(lml - float(g[tag + "_lml"])) <= LML_RTOL * abs(float(g[tag + "_lml"]))
+    dl, ds = ctx.lml_grad()
+    _, _, _, alpha, K_y = oracle.lml_and_gradient(X, y, sigma, l)
+    sl, ss = _grad_scale(oracle, X, sigma, l, alpha, K_y)
+    assert abs(dl - float(g[tag + "_l_var"])) <= GRAD_RTOL * sl
+    assert abs(ds - float(g[tag + "_sigma_var"])) <= GRAD_RTOL * ss
+    # the factor is still resident and usable afterwards
+    assert np.allclose(ctx.alpha(), g[tag + "_alpha"], rtol=0, atol=ALPHA_RTOL * np.abs(g[tag + "_alpha"]).max())
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_grad_trace_and_gradient_ascent_dropin(ctx, oracle, tag):
+    """gradient_ascent(a, b, sigma, l, alpha, K_y) with the reference's arguments (:31)."""
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    g = golden("kernels_grad")
+    X = g[tag + "_X"]
+    sigma, l = float(g[tag + "_sigma"]), float(g[tag + "_l"])
+    alpha, K_y = g[tag + "_alpha"], g[tag + "_Kyinv"]
+    dl, ds = ctx.grad_trace(X, X, sigma, l, alpha, K_y)
+    sl, ss = _grad_scale(oracle, X, sigma, l, alpha, K_y)
+    # same alpha and K_y^-1 as the reference's statement: only the summation order (tile-wise
+    # here, BLAS dot products there) and exp's last bit differ
+    assert abs(dl - float(g[tag + "_l_var"])) <= 1e-10 * sl
+    assert abs(ds - float(g[tag + "_sigma_var"])) <= 1e-10 * ss
+    s_out, l_out = T.gradient_ascent(X, X, sigma, np.array([l]), alpha.reshape(-1, 1), K_y, ctx=ctx)
+    assert s_out == sigma and l_out.shape == (1,)
+    assert abs(l_out[0] - float(g[tag + "_l_next"])) <= 1e-12 * sl          # step 0.01 x the 1e-10 above
+
+
+@pytest.mark.parametrize("nb", [128, 256, 0])
+def test_lml_grad_mid_size_and_blocking(ctx, oracle, nb):
+    X, y, _ = oracle.synthetic_problem(1500, 8, 4)
+    sigma, l = 1.2, 1.7
+    lml_o, l_var, sigma_var, alpha, K_y = oracle.lml_and_gradient(X, y, sigma, l)
+    sl, ss = _grad_scale(oracle, X, sigma, l, alpha, K_y)
+    ctx.set_option("nb", nb)
+    try:
+        lml = ctx.fit(X, y, sigma, l, 5e-4)
+        dl, ds = ctx.lml_grad()
+    finally:
+        ctx.set_option("nb", 0)
+    assert abs(lml - lml_o) <= LML_RTOL * abs(lml_o)
+    assert abs(dl - l_var) <= GRAD_RTOL * sl
+    assert abs(ds - sigma_var) <= GRAD_RTOL * ss
+
+
+def test_lml_grad_matches_finite_difference_N8192(ctx, oracle):
+    """A size no CPU inverse is asked for: central difference of the device LML."""
+    X, y, _ = oracle.synthetic_problem(8192, 8, 4)
+    sigma, l, h = 1.0, 2.0, 1e-4
+    ctx.set_train(X, y)
+    ctx.factorize(sigma, l, 5e-4)
+    dl, ds = ctx.lml_grad()
+    fd_l = (ctx.factorize(sigma, l + h, 5e-4) - ctx.factorize(sigma, l - h, 5e-4)) / (2 * h)
+    fd_s = (ctx.factorize(sigma + h, l, 5e-4) - ctx.factorize(sigma - h, l, 5e-4)) / (2 * h)
+    assert abs(dl - fd_l) <= 1e-5 * max(1.0, abs(fd_l))
+    assert abs(ds - fd_s) <= 1e-5 * max(1.0, abs(fd_s))
+
+
+def test_tune_hyperparms_first_dropin(ctx, oracle):
+    """The gradient-ascent loop (:104-162) against the oracle's restatement of it: same number
+    of iterations, same lengthscale path end, same returned posterior."""
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    np.random.seed(3)
+    f, X, y, Xs = oracle.dataset_generator(40, 25)
+    np.random.seed(11)
+    mu_o, sd_o, fp_o, lml_o, l_o, it_o = oracle.tune_hyperparms_first(X, Xs, y, 2, 1, np.array([1.5]), max_iter=400)
+    np.random.seed(11)
+    mu, sd, fp, lml, l_, it = T.tune_hyperparms_first(X, Xs, y, 2, 1, np.array([1.5]), ctx=ctx, max_iter=400,
+                                                      return_trace=True)
+    assert it == it_o
+    assert abs(l_[0] - l_o[0]) <= 1e-7
+    assert abs(lml - lml_o) <= 1e-8 * abs(lml_o)
+    assert np.allclose(mu, mu_o, atol=1e-7) and np.allclose(sd, sd_o, atol=1e-7)
+    assert np.allclose(fp, fp_o, atol=1e-5)
+    out = T.tune_hyperparms_first(X, Xs, y, 1, 1, np.array([1.5]), ctx=ctx, max_iter=5)
+    assert len(out) == 4
+
+
+def test_lml_grad_argument_errors(oracle):
+    from gaussian_process_amd import GPContext
+    c = GPContext(0)
+    with pytest.raises(ValueError):
+        c.lml_grad()                                   # nothing resident
+    X, y, _ = oracle.synthetic_problem(64, 1, 4)
+    c.set_kernel("lin", 0.5)
+    c.fit(X, y, 1.0, 1.0, 5e-4)
+    with pytest.raises(ValueError):
+        c.lml_grad()                                   # squared-exponential only
+    with pytest.raises(ValueError):
+        c.grad_trace(X, X[:10], 1.0, 1.0, y, np.eye(64))
+    c.close()
