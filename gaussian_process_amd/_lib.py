@@ -38,6 +38,8 @@ SIGNATURES = {
     "gpmi_rbf": [_vp, _dp, _i64, _dp, _i64, _i64, C.c_double, C.c_double, _dp],
     "gpmi_cov": [_vp, C.c_int, _dp, _i64, _dp, _i64, _i64, C.c_double, C.c_double, _dp],
     "gpmi_set_kernel": [_vp, C.c_int, C.c_double, C.c_double],
+    "gpmi_cov_params": [_vp, C.c_int, _dp, _i64, _dp, _i64, _i64, _dp, C.c_int, _dp],
+    "gpmi_set_kernel_params": [_vp, C.c_int, _dp, C.c_int],
     "gpmi_set_train": [_vp, _dp, _i64, _i64, _dp],
     "gpmi_factorize": [_vp, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(_i64)],
     "gpmi_fit": [_vp, _dp, _i64, _i64, _dp, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(_i64)],

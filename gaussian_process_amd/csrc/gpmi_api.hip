@@ -111,8 +111,9 @@ struct gpmi_ctx {
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
     bool have_train = false, have_factor = false;
     double sig2 = 1.0, coef = -0.5;
-    int kind = 0;            // covariance function: 0 rbf, 1 linear, 2 periodic (gpmi_set_kernel)
+    int kind = 0;            // covariance function: 0 rbf, 1 linear, 2 periodic, 3 CO2 composite (gpmi_set_kernel*)
     double kp0 = 0., kp1 = 0.;
+    double kpv[11] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
     DevBuf X, y, A, info, red;
     // test set
     int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
@@ -308,6 +309,7 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
 void set_kernel_args(const gpmi_ctx* c, RbfArgs& r) {
     r.coef = c->coef; r.sig2 = c->sig2;
     r.kind = c->kind; r.kp0 = c->kp0; r.kp1 = c->kp1;
+    for (int i = 0; i < 11; ++i) r.kpv[i] = c->kpv[i];
 }
 
 int ensure_train_buffers(gpmi_ctx* c) {
@@ -347,7 +349,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     r.A = r.B = c->X.as<double>();
     r.nA = r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->Np; r.ncols = c->Np;
     set_kernel_args(c, r);
-    r.diag_add = noise_var; r.symmetric = 1;
+    r.diag_add = noise_var; r.symmetric = 1; r.delta_square = 1;
     r.max_sq = box_max_sq(c->boxX, c->boxX);
     r.out = A; r.ld = c->ldA;
     HIP_TRY(launch_rbf(s, r));
@@ -522,6 +524,22 @@ int gpmi_set_kernel(gpmi_ctx* c, int kind, double p0, double p1) {
     return GPMI_OK;
 }
 
+int gpmi_set_kernel_params(gpmi_ctx* c, int kind, const double* params, int nparams) {
+    if (!c || !params) return fail_arg("gpmi_set_kernel_params: null argument");
+    if (kind != 3) {
+        if (kind < 0 || kind > 2 || nparams != 2) return fail_arg("gpmi_set_kernel_params: kinds 0-2 take 2 parameters");
+        return gpmi_set_kernel(c, kind, params[0], params[1]);
+    }
+    if (nparams != 11) return fail_arg("gpmi_set_kernel_params: the CO2 composite kernel takes 11 hyper-parameters (CO2_example.py:86-89)");
+    if (!(params[1] != 0.0) || !(params[3] != 0.0) || !(params[4] != 0.0) || !(params[6] != 0.0) || !(params[7] != 0.0) ||
+        !(params[9] != 0.0))
+        return fail_arg("gpmi_set_kernel_params: theta_2, 4, 5, 7, 8, 10 divide and must be non-zero");
+    c->kind = 3;
+    for (int i = 0; i < 11; ++i) c->kpv[i] = params[i];
+    c->have_factor = c->have_v = false;
+    return GPMI_OK;
+}
+
 int gpmi_sync(gpmi_ctx* c) {
     if (!c) return fail_arg("gpmi_sync: null context");
     HIP_TRY(hipSetDevice(c->device));
@@ -529,20 +547,39 @@ int gpmi_sync(gpmi_ctx* c) {
     return GPMI_OK;
 }
 
+static int cov_impl(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
+                    double p0, double p1, const double* kpv, double* out);
+
 int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
-             double p0, double p1, double* out);
+             double p0, double p1, double* out) {
+    if (kind < 0 || kind > 2) return fail_arg("gpmi_cov: kind must be 0, 1 or 2");
+    return cov_impl(c, kind, a, N, b, M, d, p0, p1, nullptr, out);
+}
+
+int gpmi_cov_params(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
+                    const double* params, int nparams, double* out) {
+    if (!params) return fail_arg("gpmi_cov_params: null parameters");
+    if (kind != 3) {
+        if (kind < 0 || kind > 2 || nparams != 2) return fail_arg("gpmi_cov_params: kinds 0-2 take 2 parameters");
+        return cov_impl(c, kind, a, N, b, M, d, params[0], params[1], nullptr, out);
+    }
+    if (nparams != 11) return fail_arg("gpmi_cov_params: the CO2 composite kernel takes 11 hyper-parameters");
+    if (!(params[1] != 0.0) || !(params[3] != 0.0) || !(params[4] != 0.0) || !(params[6] != 0.0) || !(params[7] != 0.0) ||
+        !(params[9] != 0.0))
+        return fail_arg("gpmi_cov_params: theta_2, 4, 5, 7, 8, 10 divide and must be non-zero");
+    return cov_impl(c, 3, a, N, b, M, d, 0., 0., params, out);
+}
 
 int gpmi_rbf(gpmi_ctx* c, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
              double sigma, double ell, double* out) {
     return gpmi_cov(c, 0, a, N, b, M, d, sigma, ell, out);
 }
 
-int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
-             double p0, double p1, double* out) {
+static int cov_impl(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b, int64_t M, int64_t d,
+                    double p0, double p1, const double* kpv, double* out) {
     const double sigma = p0, ell = p1;
     if (!c || !a || !b || !out) return fail_arg("gpmi_rbf: null argument");
     if (N < 0 || M < 0 || d <= 0) return fail_arg("gpmi_rbf: bad dimensions");
-    if (kind < 0 || kind > 2) return fail_arg("gpmi_cov: kind must be 0, 1 or 2");
     if (kind == 0 && !(ell != 0.0)) return fail_arg("gpmi_rbf: ell must be non-zero");
     if (kind == 2 && (d != 1 || !(p0 != 0.0) || !(p1 != 0.0)))
         return fail_arg("gpmi_cov: the periodic kernel is 1-D with non-zero period and lengthscale");
@@ -577,6 +614,8 @@ int gpmi_cov(gpmi_ctx* c, int kind, const double* a, int64_t N, const double* b,
             r.nA = N; r.nB = M; r.d = d; r.row0 = r0; r.nrows = round_up(rows, TILE); r.ncols = Mp;
             r.coef = (kind == 0) ? -.5 * (1 / (ell * ell)) : 0.; r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
             r.kind = kind; r.kp0 = p0; r.kp1 = p1;
+            if (kpv) for (int i = 0; i < 11; ++i) r.kpv[i] = kpv[i];
+            r.delta_square = (N == M) ? 1 : 0;
             r.max_sq = max_sq;
             r.out = dout.as<double>(); r.ld = ld;
             if ((e = launch_rbf(s, r)) != hipSuccess) { rc = fail_runtime(e, "rbf kernel"); break; }
@@ -713,6 +752,7 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     r.nA = c->n; r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->np_; r.ncols = c->Np;
     set_kernel_args(c, r);
     r.diag_add = 0.; r.symmetric = 0;
+    r.delta_square = (c->n == c->N) ? 1 : 0;   // kernel_4's delta is eye whenever the matrix is square (CO2_example.py:58)
     r.max_sq = box_max_sq(c->boxXs, c->boxX);
     r.out = V; r.ld = c->ldV;
     HIP_TRY(launch_rbf(s, r));
@@ -738,6 +778,10 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
         if (out2) {
             double kss = c->sig2;                          // diag(K_ss) == sigma^2 exactly for the RBF (GP_regression.py:147)
             if (c->kind == 2) kss = 1.0;                   // periodic: exp(0)
+            else if (c->kind == 3) {                       // composite at sqdist 0, square K_ss: every factor is 1
+                const double* th = c->kpv;
+                kss = ((th[0] * th[0] + th[2] * th[2]) + th[5] * th[5]) + (th[8] * th[8] + th[10] * th[10]);
+            }
             else if (c->kind == 1) {                       // linear: (x - c).(x - c)
                 kss = 0.0;
                 for (int64_t k = 0; k < c->d; ++k) {
@@ -893,7 +937,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     r.A = r.B = c->Xs.as<double>();
     r.nA = r.nB = n; r.d = c->d; r.row0 = 0; r.nrows = np_; r.ncols = np_;
     set_kernel_args(c, r);
-    r.diag_add = jitter; r.symmetric = 1;
+    r.diag_add = jitter; r.symmetric = 1; r.delta_square = 1;
     r.max_sq = box_max_sq(c->boxXs, c->boxXs);
     r.out = P; r.ld = c->ldP;
     HIP_TRY(launch_rbf(s, r));

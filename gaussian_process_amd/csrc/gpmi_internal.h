@@ -70,8 +70,11 @@ struct RbfArgs {
     // covariance function: 0 squared-exponential (coef, sig2 above);
     // 1 linear  sum_k (a_k - c)(b_k - c), c = kp0            (GP_regression.py:22-33)
     // 2 periodic exp(-2 sin^2(pi |a-b| / p) / l^2), p = kp0, l = kp1, d == 1 (GP_regression.py:36-50)
+    // 3 CO2 composite: kernel_1 + kernel_2 + kernel_3 + kernel_4 with theta_1..11 = kpv (CO2_example.py:9-94)
     int kind = 0;
     double kp0 = 0., kp1 = 0.;
+    double kpv[11] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+    int delta_square = 0;     // kind 3: the reference's output is square -> kernel_4 adds theta_11^2 * eye (:58-59)
     // upper bound of |a_i - b_j|^2 over the whole launch (from the inputs' bounding boxes), or < 0
     // when unknown: lets the squared-exponential build skip its per-wave exp domain test
     double max_sq = -1.0;

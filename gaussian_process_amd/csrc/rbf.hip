@@ -41,6 +41,8 @@ struct RbfDev {
     int64_t ld;
     int kind;
     double kp0, kp1;
+    double kpv[11];        // kind 3: theta_1 .. theta_11 of the CO2 composite kernel
+    int delta_square;      // kind 3: the output is square, so kernel_4 adds theta_11^2 on row == col
     int nocheck;           // host-proved: every exp argument of this launch lies in [-700, 0]
     int strip;             // rbf_regs_kernel: row tiles per work item
     int nitems;            // rbf_regs_kernel: strips x column tiles
@@ -382,14 +384,33 @@ __global__ __launch_bounds__(256) void rbf_naive_kernel(const RbfDev p) {
     }
 }
 
-// The reference's other two covariance functions, one column pair per
+// The reference's other covariance functions, one column pair per
 // thread straight from global memory: these matrices are built once per fit, the work is in
 // the factorisation.
-__device__ __forceinline__ double cov_other(const RbfDev& p, const double* a, const double* b) {
+//   kind 1  lin_kernel                                   GP_regression.py:22-33
+//   kind 2  per_kernel (1-D)                             GP_regression.py:36-50
+//   kind 3  covariance_function = kernel_1 + kernel_2 + kernel_3 + kernel_4 (RBF + decaying
+//           periodic + rational quadratic + noise), any d             CO2_example.py:9-94
+__device__ __forceinline__ double cov_other(const RbfDev& p, const double* a, const double* b, bool diag) {
     if (p.kind == 1) {                         // lin_kernel: np.dot(a - c, b.T - c)
         double s = 0.0;
         for (int k = 0; k < p.d; ++k) s = s + (a[k] - p.kp0) * (b[k] - p.kp0);
         return s;
+    }
+    if (p.kind == 3) {
+        const double* th = p.kpv;              // th[i] = theta_(i+1)
+        const double sq = sq_pw_global(a, b, p.d);                                   // CO2_example.py:76 / :83
+        const double r = sqrt(sq);                                                   // :77 / :85
+        const double k1 = (th[0] * th[0]) * exp(-.5 * sq / (th[1] * th[1]));         // :17
+        const double first = -.5 * sq / (th[3] * th[3]);                             // :30
+        const double sn = sin(M_PI * r) / th[4];
+        const double second = -2 * (sn * sn);                                        // :31
+        const double k2 = (th[2] * th[2]) * exp(first + second);                     // :32
+        const double item = 1 + .5 * sq / (th[7] * (th[6] * th[6]));                 // :44
+        const double k3 = (th[5] * th[5]) * (1.0 / pow(item, th[7]));                // :45-46
+        const double delta = (p.delta_square && diag) ? 1.0 : 0.0;                   // :58-62
+        const double k4 = (th[8] * th[8]) * exp(-.5 * sq / (th[9] * th[9])) + (th[10] * th[10]) * delta;   // :63-64
+        return ((k1 + k2) + k3) + k4;                                                // :86-89
     }
     // per_kernel (1-D): exp(-2 * sin(pi * |a-b| / p)**2 / l**2), evaluated in the reference's order
     const double t = fabs(a[0] - b[0]);
@@ -409,8 +430,8 @@ __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
         const int64_t gr = grow0 + 32 * rg + r;
         double v0 = 0., v1 = 0.;
         if (gr < p.nA) {
-            if (gc < p.nB) v0 = cov_other(p, p.A + gr * d, p.B + gc * d);
-            if (gc + 1 < p.nB) v1 = cov_other(p, p.A + gr * d, p.B + (gc + 1) * d);
+            if (gc < p.nB) v0 = cov_other(p, p.A + gr * d, p.B + gc * d, gr == gc);
+            if (gc + 1 < p.nB) v1 = cov_other(p, p.A + gr * d, p.B + (gc + 1) * d, gr == gc + 1);
         }
         cov_store(p, gr, gc, v0, v1, p.out + ((int64_t)ti * RT + 32 * rg + r) * p.ld + gc);
     }
@@ -428,9 +449,11 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     p.coef = a.coef; p.sig2 = a.sig2; p.diag_add = a.diag_add; p.symmetric = a.symmetric;
     p.out = a.out; p.ld = a.ld;
     p.kind = a.kind; p.kp0 = a.kp0; p.kp1 = a.kp1;
+    for (int i = 0; i < 11; ++i) p.kpv[i] = a.kpv[i];
+    p.delta_square = a.delta_square;
     // coef <= 0 and max_sq bounds every squared distance of this launch (NaN / unknown fail the test)
     p.nocheck = (a.max_sq >= 0.0 && a.coef <= 0.0 && a.coef * a.max_sq * 1.000001 >= -690.0) ? 1 : 0;
-    if (a.kind < 0 || a.kind > 2 || (a.kind == 2 && a.d != 1)) return hipErrorInvalidValue;
+    if (a.kind < 0 || a.kind > 3 || (a.kind == 2 && a.d != 1)) return hipErrorInvalidValue;
     p.tri = (a.symmetric && a.row0 == 0 && p.Tm == p.Tn) ? 1 : 0;
     const int64_t nblk = p.tri ? (int64_t)p.Tm * (p.Tm + 1) / 2 : (int64_t)p.Tm * p.Tn;
     dim3 grid((unsigned)nblk), block(256);

@@ -92,7 +92,7 @@ class GPContext:
                                  scalar(sigma, "sigma"), scalar(l, "l"), ptr(out)))
         return out
 
-    KINDS = {"rbf": 0, "lin": 1, "per": 2}
+    KINDS = {"rbf": 0, "lin": 1, "per": 2, "co2": 3}
 
     def cov(self, kind, a, b, p0, p1=0.0):
         """kernel matrix of the reference's covariance functions: 'rbf' (p0 = sigma, p1 = l),
@@ -102,12 +102,22 @@ class GPContext:
         if a.shape[1] != b.shape[1]:
             raise ValueError("a and b must have the same number of columns (d): %s vs %s" % (a.shape, b.shape))
         out = np.empty((a.shape[0], b.shape[0]), dtype=np.float64)
+        if kind == "co2":                     # p0 = the 11 hyper-parameters (CO2_example.py:86-89)
+            th = as_f64(np.asarray(p0, dtype=np.float64).reshape(-1), 1, "hyperparms")
+            check(self._lib.gpmi_cov_params(self._h, 3, ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
+                                            ptr(th), th.shape[0], ptr(out)))
+            return out
         check(self._lib.gpmi_cov(self._h, self.KINDS[kind], ptr(a), a.shape[0], ptr(b), b.shape[0], a.shape[1],
                                  scalar(p0, "p0"), scalar(p1, "p1"), ptr(out)))
         return out
 
     def set_kernel(self, kind, p0=0.0, p1=0.0):
-        """covariance function of the following fit / predict calls (kernel_choice of prediction())"""
+        """covariance function of the following fit / predict calls (kernel_choice of prediction());
+        'co2': p0 = the 11 hyper-parameters of CO2_example.py's covariance_function"""
+        if kind == "co2":
+            th = as_f64(np.asarray(p0, dtype=np.float64).reshape(-1), 1, "hyperparms")
+            check(self._lib.gpmi_set_kernel_params(self._h, 3, ptr(th), th.shape[0]))
+            return
         check(self._lib.gpmi_set_kernel(self._h, self.KINDS[kind], scalar(p0, "p0"), scalar(p1, "p1")))
 
     # ---- fit --------------------------------------------------------------------------

@@ -84,6 +84,15 @@ int gpmi_cov(gpmi_ctx* ctx, int kind, const double* a, int64_t N, const double* 
  * (kernel_choice of prediction(), GP_regression.py:125-136).  kind 0 (default) takes sigma and l
  * from gpmi_factorize; kinds 1, 2 take (p0, p1) as above and ignore them. */
 int gpmi_set_kernel(gpmi_ctx* ctx, int kind, double p0, double p1);
+/* The composite covariance of the CO2 example (second half):
+ *   kind 3: covariance_function(a, b, hyperparms) = kernel_1 + kernel_2 + kernel_3 + kernel_4,
+ *           hyperparms = theta_1..theta_11, any d                            CO2_example.py:9-94
+ * kernel_4 adds theta_11^2 on row == col whenever the matrix is square (N == M), as the reference
+ * does (:58-59).  The *_params forms take the parameters as an array; kinds 0-2 accept
+ * nparams == 2 with (p0, p1) as above. */
+int gpmi_cov_params(gpmi_ctx* ctx, int kind, const double* a, int64_t N, const double* b, int64_t M,
+                    int64_t d, const double* params, int nparams, double* out);
+int gpmi_set_kernel_params(gpmi_ctx* ctx, int kind, const double* params, int nparams);
 
 /* Copy the training set to the device (X: N x d, y: N).  Replaces nothing in
  * the reference (it has no device); separates PCIe from the timed path. */

@@ -268,6 +268,76 @@ def tune_hyperparms_first(X_train, X_test, y_train, num_fun, sigma, l, max_iter=
 
 
 # ---------------------------------------------------------------------------
+# SURVEY.md section 8f row f4 (second half): the composite covariance of CO2_example.py
+# (Python-2 file, not importable; restated statement by statement)
+# ---------------------------------------------------------------------------
+def co2_covariance_function(a, b, hyperparms):
+    """CO2_example.py:66-90 with kernel_1..kernel_4 (:9-64) inlined in the same order."""
+    if a.shape[1] == 1 and b.shape[1] == 1:                                            # :75
+        sqdist = ((a[:, :, None] - b[:, :, None].T) ** 2).sum(1)                       # :76
+        l2_norm = np.sqrt(sqdist)                                                      # :77
+    else:
+        sqdist = (((a[:, None, :] - b[None, :, :]) ** 2).sum(axis=2))                  # :83
+        l2_norm = np.sqrt(sqdist)                                                      # :85
+    t = hyperparms
+    k1 = (t[0] ** 2) * np.exp(-.5 * sqdist / t[1] ** 2)                                # :17
+    first_item = -.5 * sqdist / t[3] ** 2                                              # :30
+    second_item = -2 * ((np.sin(np.pi * l2_norm)) / t[4]) ** 2                         # :31
+    k2 = t[2] ** 2 * np.exp(first_item + second_item)                                  # :32
+    item = 1 + .5 * sqdist / (t[7] * t[6] ** 2)                                        # :44
+    k3 = t[5] ** 2 * (1.0 / np.power(item, t[7]))                                      # :45-46
+    n = len(sqdist)
+    delta = np.eye(n) if sqdist.shape[0] == sqdist.shape[1] else 0                     # :58-62
+    k4 = t[8] ** 2 * np.exp(-.5 * sqdist / t[9] ** 2) + t[10] ** 2 * delta             # :63-64
+    return k1 + k2 + k3 + k4                                                           # :86-89
+
+
+def co2_compute_mar_likelihood(X_train, y_train, hyperparms):
+    """CO2_example.py:125-142 (alpha through the explicit inverse of L, as there)."""
+    s = NOISE_VAR                                                                      # :133
+    n = len(X_train)
+    K_train = co2_covariance_function(X_train, X_train, hyperparms)                    # :135
+    L = np.linalg.cholesky(K_train + s * np.eye(n))                                    # :136
+    L_inv = np.linalg.inv(L)                                                           # :137
+    alpha = np.dot(L_inv.T, np.dot(L_inv, y_train))                                    # :138
+    return (-.5 * np.dot(y_train.T, alpha) - np.log(np.diagonal(L)).sum(0)
+            - n / 2.0 * np.log(2 * np.pi))                                             # :140
+
+
+def co2_posterior(X_train, X_test, y_train, hyperparms, s):
+    """The body shared by bayesian_opt (:155-171) and make_prediction (:183-198)."""
+    n = len(X_train)
+    K = co2_covariance_function(X_train, X_train, hyperparms)
+    K_s = co2_covariance_function(X_train, X_test, hyperparms)
+    K_ss = co2_covariance_function(X_test, X_test, hyperparms)
+    L = np.linalg.cholesky(K + s * np.eye(n))
+    L_inv = np.linalg.inv(L)
+    alpha = np.dot(L_inv.T, np.dot(L_inv, y_train))
+    mu_post = np.dot(K_s.T, alpha)
+    v = np.dot(L_inv, K_s)
+    var_test = np.diag(K_ss) - np.sum(v ** 2, axis=0)
+    with np.errstate(invalid='ignore'):
+        stand_devi = np.sqrt(var_test)
+    return mu_post, stand_devi, K_ss, v
+
+
+def co2_bayesian_opt(hyperparms_train, hyperparms_test, y_train):
+    """CO2_example.py:145-172: GP over hyper-parameter vectors with the composite kernel whose own
+    hyper-parameters are the first training vector (:157); s = 1e-4; returns (mu, sd)."""
+    mu, sd, _, _ = co2_posterior(hyperparms_train, hyperparms_test, y_train, hyperparms_train[0], BO_NOISE_VAR)
+    return mu, sd
+
+
+def co2_make_prediction(X_train, X_test, y_train, hyperparms):
+    """CO2_example.py:175-203: s = 5e-4, one posterior sample."""
+    N = len(X_test)
+    mu, sd, K_ss, v = co2_posterior(X_train, X_test, y_train, hyperparms, NOISE_VAR)
+    L_ = np.linalg.cholesky(K_ss + POST_JITTER * np.eye(N) - np.dot(v.T, v))           # :201
+    f_post_fun = mu.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(N, 1)))         # :202
+    return mu, sd, f_post_fun
+
+
+# ---------------------------------------------------------------------------
 # Memory-feasible restatement (BASELINE.md section 3): identical K arithmetic, but true
 # triangular solves instead of LU on a triangular matrix.  Used as the CPU
 # baseline at sizes where the (N,d,N) broadcast does not fit, and as the

@@ -5,10 +5,18 @@ sees the reference, it gets the committed .npz fixtures.  The fixtures hold
 data only -- inputs and the reference's outputs on them.
 
 What is imported:  /root/reference/GP_regression.py  (Python 3 clean).
-What cannot be:    tune_hyperparms_regression.py is Python-2 syntax
-                   (first SyntaxError at :150), so the LML goldens are produced
-                   by issuing its lines :306-312 here, with the IMPORTED
-                   RBF_kernel and the same np.linalg calls.
+What cannot be:    tune_hyperparms_regression.py and CO2_example.py are Python-2 modules
+                   (print statements; first SyntaxError at tune...:150), so they cannot be
+                   imported whole.  Most of their FUNCTIONS are valid Python 3 on their own,
+                   though: `ref_functions` below reads the file, cuts out the named top-level
+                   `def` blocks and executes exactly that source text (nothing is copied into
+                   this repository) with NumPy and the imported RBF_kernel in scope.  That is
+                   how compute_mar_likelihood, gradient_ascent, bayesian_opt and the CO2
+                   example's covariance_function / compute_mar_likelihood / bayesian_opt /
+                   make_prediction produce the vectors here.  Intermediate quantities the
+                   reference does not return (diag L, m, alpha, the two gradient traces) are
+                   produced by issuing the reference's statements with the same NumPy calls,
+                   and asserted against the executed functions where they overlap.
 
 usage:  MPLBACKEND=Agg python oracle/make_golden.py
 """
@@ -24,6 +32,36 @@ import GP_regression as REF  # noqa: E402  (the reference)
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
+def ref_functions(path, names, namespace):
+    """Execute the source of the named top-level functions of a reference file (read as text,
+    in this container only) inside `namespace`; returns the namespace."""
+    import re
+    lines = open(path, newline=None).read().split("\n")
+    blocks, cur, buf = {}, None, []
+    for ln in lines:
+        m = re.match(r"^def\s+(\w+)\s*\(", ln)
+        if m:
+            if cur:
+                blocks[cur] = "\n".join(buf)
+            cur, buf = m.group(1), [ln]
+        elif cur:
+            if re.match(r"^\S", ln):
+                blocks[cur] = "\n".join(buf)
+                cur, buf = None, []
+            else:
+                buf.append(ln)
+    if cur:
+        blocks[cur] = "\n".join(buf)
+    for name in names:
+        exec(compile(blocks[name], "%s:%s" % (path, name), "exec"), namespace)
+    return namespace
+
+
+TUNE = ref_functions("/root/reference/tune_hyperparms_regression.py",
+                     ["compute_mar_likelihood", "gradient_ascent", "bayesian_opt"],
+                     {"np": np, "RBF_kernel": REF.RBF_kernel})
+
+
 def ref_lml(X, y, sigma, l, s=0.0005):
     # tune_hyperparms_regression.py:303-312 issued with the imported RBF_kernel
     n = len(X)
@@ -32,6 +70,9 @@ def ref_lml(X, y, sigma, l, s=0.0005):
     m = np.linalg.solve(L, y)
     alpha = np.linalg.solve(L.T, m)
     lml = -.5 * np.dot(y.T, alpha) - np.log(np.diagonal(L)).sum(0) - n / 2.0 * np.log(2 * np.pi)
+    if s == 0.0005:
+        # the reference's own function (executed from its source) returns the same number
+        assert TUNE["compute_mar_likelihood"](X, None, y, sigma, l) == lml
     return lml, L, m, alpha
 
 
@@ -154,12 +195,57 @@ def grad_cases():
         sigma_var = .5 * np.diagonal(np.dot(np.dot(al, al.T) - K_y, sigma_grad)).sum()   # :49-51
         l_grad = sigma ** 2 * np.exp(-.5 * sqdist / (l ** 2)) * (sqdist / l ** 3)   # :54
         l_var = .5 * np.diagonal(np.dot(np.dot(al, al.T) - K_y, l_grad)).sum()      # :55-57
+        s_ref, l_ref = TUNE["gradient_ascent"](X, X, sigma, l, al, K_y)     # the reference's function itself (:31-64)
+        assert s_ref == sigma and l_ref == l + 0.01 * l_var
         out.update({tag + "_X": X, tag + "_y": y, tag + "_sigma": sigma, tag + "_l": l, tag + "_lml": lml,
                     tag + "_alpha": alpha, tag + "_l_var": l_var, tag + "_sigma_var": sigma_var,
                     tag + "_l_next": l + 0.01 * l_var})                              # :42, :63
         if N <= 200:
             out[tag + "_Kyinv"] = K_y          # the larger inverse is recomputed by the tests (fixture size)
     np.savez_compressed(os.path.join(OUT, "kernels_grad.npz"), **out)
+
+
+def bo_and_co2_cases():
+    """(1) tune_hyperparms_regression.bayesian_opt (:67-101) executed from the reference source.
+    (2) CO2_example.py: covariance_function (+ kernel_1..4), compute_mar_likelihood, bayesian_opt and
+    make_prediction executed from the reference source (second half).  The Mauna Loa data
+    set is a network fetch in the reference (:405) and is not used: inputs are synthetic with
+    the same shape (monthly decimal years, 1-D)."""
+    out = {}
+    rng = np.random.default_rng(77)
+    # (1)
+    lt = np.array([0.4, 1.1, 2.3, 3.1, 4.6]).reshape(-1, 1)
+    lq = np.sort(rng.uniform(0.02, 5, 60)).reshape(-1, 1)
+    yl = np.array([-310.2, 210.5, 402.75, 380.1, 150.9])
+    np.random.seed(21)
+    mu, sd, fp = TUNE["bayesian_opt"](lt, lq, yl)
+    out.update(bo_X=lt, bo_Xs=lq, bo_y=yl, bo_mu=mu, bo_sd=sd, bo_fpost=fp)
+    # (2)
+    CO2 = ref_functions("/root/reference/CO2_example.py",
+                        ["kernel_1", "kernel_2", "kernel_3", "kernel_4", "covariance_function",
+                         "compute_mar_likelihood", "bayesian_opt", "make_prediction", "init_hyperms"],
+                        {"np": np})
+    book = np.array([66, 67, 2.4, 90, 1.3, .66, 1.2, .78, .18, 1.6, .19])             # :120, :323
+    X = (1958.0 + np.arange(360) / 12.0 + 0.04).reshape(-1, 1)
+    y = 0.11 * (X[:, 0] - 1958) ** 1.5 + 3 * np.sin(2 * np.pi * X[:, 0]) + 0.3 * rng.standard_normal(360)
+    y = y - np.mean(y)
+    Xs = (1988.0 + np.arange(48) / 12.0 + 0.04).reshape(-1, 1)
+    K = CO2["covariance_function"](X, X, book)
+    Ks = CO2["covariance_function"](X, Xs, book)
+    Ksq = CO2["covariance_function"](X[:48], Xs, book)          # square but a != b: the delta quirk (:58)
+    out.update(co2_theta=book, co2_X=X, co2_y=y, co2_Xs=Xs, co2_K_corner=K[:16, :16].copy(), co2_K_rowsum=K.sum(1),
+               co2_K_lastrow=K[-1].copy(), co2_Ks=Ks, co2_Ksq=Ksq,
+               co2_lml=CO2["compute_mar_likelihood"](X, y, book))
+    np.random.seed(31)
+    mu, sd, fp = CO2["make_prediction"](X, Xs, y, book)
+    out.update(co2_mu=mu, co2_sd=sd, co2_fpost=fp)
+    hp = CO2["init_hyperms"](5, 11)                                                    # :296-306
+    hq = hp[0] + rng.uniform(-3, 6, (40, 11))
+    lmls = np.array([CO2["compute_mar_likelihood"](X, y, h) for h in hp])              # :338-339
+    mu, sd = CO2["bayesian_opt"](hp, hq, lmls)                                         # :341 (multi-D branch :83)
+    out.update(co2_hp=hp, co2_hq=hq, co2_hp_lml=lmls, co2_bo_mu=mu, co2_bo_sd=sd,
+               co2_Khp=CO2["covariance_function"](hp, hq, hp[0]))
+    np.savez_compressed(os.path.join(OUT, "kernels_bo_co2.npz"), **out)
 
 
 if __name__ == "__main__":
@@ -173,4 +259,5 @@ if __name__ == "__main__":
     edge_cases()
     other_kernels()
     grad_cases()
+    bo_and_co2_cases()
     print("wrote", sorted(os.listdir(OUT)))

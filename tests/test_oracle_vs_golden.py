@@ -149,3 +149,33 @@ def test_gradient_ascent_loop_converges(oracle):
     assert it < 400 and mu.shape == (25,) and sd.shape == (25,) and fp.shape == (25, 2)
     _, l_var, _, _, _ = oracle.lml_and_gradient(X, y, 1, float(l[0]))
     assert abs(0.01 * l_var) < 1e-2          # the step that would follow is small
+
+
+def test_bayesian_opt_vs_reference_function(oracle):
+    """tune_hyperparms_regression.bayesian_opt (:67-101), vectors from the reference's function itself."""
+    g = golden("kernels_bo_co2")
+    np.random.seed(21)
+    mu, sd, fp = oracle.bayesian_opt(g["bo_X"], g["bo_Xs"], g["bo_y"])
+    assert np.allclose(mu, g["bo_mu"], rtol=0, atol=1e-9 * np.abs(g["bo_mu"]).max())
+    assert np.allclose(sd, g["bo_sd"], rtol=0, atol=1e-9, equal_nan=True)
+    assert np.allclose(fp, g["bo_fpost"], rtol=0, atol=1e-6 * np.abs(g["bo_fpost"]).max())
+
+
+def test_co2_composite_kernel_and_paths(oracle):
+    """SURVEY.md section 8f row f4, second half: CO2_example.py's covariance_function, compute_mar_likelihood,
+    make_prediction and bayesian_opt; vectors produced by executing the reference's own
+    function source (oracle/make_golden.py)."""
+    g = golden("kernels_bo_co2")
+    th, X, y, Xs = g["co2_theta"], g["co2_X"], g["co2_y"], g["co2_Xs"]
+    K = oracle.co2_covariance_function(X, X, th)
+    assert np.array_equal(K[:16, :16], g["co2_K_corner"]) and np.array_equal(K[-1], g["co2_K_lastrow"])
+    assert np.array_equal(oracle.co2_covariance_function(X, Xs, th), g["co2_Ks"])
+    assert np.array_equal(oracle.co2_covariance_function(X[:48], Xs, th), g["co2_Ksq"])     # square: delta added
+    assert oracle.co2_compute_mar_likelihood(X, y, th) == float(g["co2_lml"])
+    np.random.seed(31)
+    mu, sd, fp = oracle.co2_make_prediction(X, Xs, y, th)
+    assert np.array_equal(mu, g["co2_mu"]) and np.array_equal(sd, g["co2_sd"], equal_nan=True)
+    assert np.array_equal(fp, g["co2_fpost"])
+    mu, sd = oracle.co2_bayesian_opt(g["co2_hp"], g["co2_hq"], g["co2_hp_lml"])
+    assert np.array_equal(mu, g["co2_bo_mu"]) and np.array_equal(sd, g["co2_bo_sd"], equal_nan=True)
+    assert np.array_equal(oracle.co2_covariance_function(g["co2_hp"], g["co2_hq"], g["co2_hp"][0]), g["co2_Khp"])

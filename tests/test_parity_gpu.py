@@ -510,3 +510,65 @@ def test_lml_grad_argument_errors(oracle):
     with pytest.raises(ValueError):
         c.grad_trace(X, X[:10], 1.0, 1.0, y, np.eye(64))
     c.close()
+
+
+# ----------------------------------------------------------------------------- f4: CO2 composite kernel
+CO2_K_RTOL = 2e-14    # sin, pow and three exps per element, each within ~1 ulp of NumPy's
+
+
+def test_co2_composite_kernel_vs_reference_function(ctx):
+    """covariance_function of CO2_example.py (:66-90): vectors from the reference's own source."""
+    from gaussian_process_amd import CO2_example as C2
+    g = golden("kernels_bo_co2")
+    th, X, Xs = g["co2_theta"], g["co2_X"], g["co2_Xs"]
+    K = C2.covariance_function(X, X, th, ctx=ctx)
+    assert np.allclose(K[:16, :16], g["co2_K_corner"], rtol=CO2_K_RTOL, atol=0)
+    assert np.allclose(K[-1], g["co2_K_lastrow"], rtol=CO2_K_RTOL, atol=0)
+    assert np.allclose(K.sum(1), g["co2_K_rowsum"], rtol=1e-13, atol=0)
+    assert np.array_equal(K, K.T)
+    assert np.allclose(C2.covariance_function(X, Xs, th, ctx=ctx), g["co2_Ks"], rtol=CO2_K_RTOL, atol=0)
+    # square with a != b: kernel_4 still adds theta_11^2 on row == col (:58)
+    assert np.allclose(C2.covariance_function(X[:48], Xs, th, ctx=ctx), g["co2_Ksq"], rtol=CO2_K_RTOL, atol=0)
+    # multi-dimensional branch (:83): hyper-parameter vectors as inputs
+    assert np.allclose(C2.covariance_function(g["co2_hp"], g["co2_hq"], g["co2_hp"][0], ctx=ctx), g["co2_Khp"],
+                       rtol=CO2_K_RTOL, atol=0)
+    with pytest.raises(ValueError):
+        ctx.cov("co2", X, Xs, th[:5])
+
+
+def test_co2_fit_predict_vs_reference_functions(ctx):
+    """compute_mar_likelihood (:125-142), make_prediction (:175-203), bayesian_opt (:145-172)."""
+    from gaussian_process_amd import CO2_example as C2
+    g = golden("kernels_bo_co2")
+    th, X, y, Xs = g["co2_theta"], g["co2_X"], g["co2_y"], g["co2_Xs"]
+    lml = C2.compute_mar_likelihood(X, y, th, ctx=ctx)
+    assert abs(lml - float(g["co2_lml"])) <= 1e-9 * abs(float(g["co2_lml"]))    # the reference inverts L explicitly
+    np.random.seed(31)
+    mu, sd, fp = C2.make_prediction(X, Xs, y, th, ctx=ctx)
+    scale = np.abs(g["co2_mu"]).max()
+    assert np.allclose(mu, g["co2_mu"], rtol=0, atol=1e-8 * scale)
+    assert np.allclose(sd, g["co2_sd"], rtol=0, atol=1e-8, equal_nan=True)
+    assert np.allclose(fp, g["co2_fpost"], rtol=0, atol=1e-5 * scale)
+    mu, sd = C2.bayesian_opt(g["co2_hp"], g["co2_hq"], g["co2_hp_lml"], ctx=ctx)
+    assert np.allclose(mu, g["co2_bo_mu"], rtol=0, atol=1e-8 * np.abs(g["co2_bo_mu"]).max())
+    assert np.allclose(sd, g["co2_bo_sd"], rtol=0, atol=1e-6, equal_nan=True)
+    # the context is back on the squared-exponential kernel afterwards
+    gg = golden("d8_box1_N64")
+    assert abs(ctx.fit(gg["X"], gg["y"], 1.0, float(gg["ell"]), 5e-4) - float(gg["lml"])) <= LML_RTOL * abs(float(gg["lml"]))
+
+
+def test_co2_bo_loop_runs(ctx):
+    """The 11-parameter BO loop (:309-371) end to end on a small synthetic series: every LML
+    it evaluates is a real GPU fit; the best vector it returns has the largest LML seen."""
+    import random
+    from gaussian_process_amd import CO2_example as C2
+    g = golden("kernels_bo_co2")
+    X, y, Xs = g["co2_X"][:120], g["co2_y"][:120], g["co2_Xs"]
+    random.seed(5)
+    np.random.seed(5)
+    best, traces = C2.tune_hyperparameters_BO(X, Xs, y, choices=("UBC", "EI", "PI", "TS"), num_iterations=3,
+                                              n_hyperparms_test=40, ctx=ctx, return_trace=True)
+    assert best.shape == (11,) and set(traces) == {"UBC", "EI", "PI", "TS"}
+    for t in traces.values():
+        nz = t[t != 0]
+        assert np.all(np.diff(nz) >= 0)          # running maximum of the LMLs seen so far
