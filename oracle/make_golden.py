@@ -248,6 +248,34 @@ def bo_and_co2_cases():
     np.savez_compressed(os.path.join(OUT, "kernels_bo_co2.npz"), **out)
 
 
+def acquisition_cases():
+    """UCB / EI / TS (tune_hyperparms_regression.py:207-268) and overlap (:316-328)
+    executed from the reference source (PI has a Python-2 print and cannot be)."""
+    from scipy.stats import norm
+    import matplotlib.pyplot as plt
+    A = ref_functions("/root/reference/tune_hyperparms_regression.py", ["UCB", "EI", "TS", "overlap"],
+                      {"np": np, "norm": norm, "plt": plt, "prediction": REF.prediction})
+    rng = np.random.default_rng(91)
+    done = np.array([0.4, 1.1, 2.3, 3.1, 4.6])
+    y = np.array([-310.2, 210.5, 402.75, 380.1, 150.9])
+    params = np.sort(rng.uniform(0.02, 5, 60)).reshape(-1, 1)
+    np.random.seed(21)
+    mu, sd, _ = TUNE["bayesian_opt"](done.reshape(-1, 1), params, y)
+    out = dict(done=done, y=y, params=params, mu=mu, sd=sd)
+    out["ucb"] = np.asarray(A["UCB"](done, params, mu, sd, 3, 0))
+    out["ei"] = np.asarray(A["EI"](params, mu, sd, done, y, 3, 0))
+    np.random.seed(22)
+    out["ts"] = np.asarray(A["TS"](done, params, y, 3, 0))
+    # UCB's stop rule: proposing the last evaluated point again returns True
+    params2 = params.copy(); j = int(np.argmax(mu + 0.001 * sd)); done2 = np.append(done, params2[j, 0])
+    out["ucb_stop"] = np.asarray(A["UCB"](done2, params2, mu, sd, 3, 0) is True)
+    grid = np.linspace(0.01, 5, 75)
+    a = np.array([grid[3], 0.777, grid[40], grid[74]])
+    ia, ib = A["overlap"](a, grid)
+    out.update(ov_a=a, ov_b=grid, ov_ia=ia, ov_ib=ib)
+    np.savez_compressed(os.path.join(OUT, "kernels_acq.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for sd_ in (0, 1, 2):
@@ -260,4 +288,5 @@ if __name__ == "__main__":
     other_kernels()
     grad_cases()
     bo_and_co2_cases()
+    acquisition_cases()
     print("wrote", sorted(os.listdir(OUT)))

@@ -88,3 +88,17 @@ def test_candidate_sampling():
     assert np.all((cand >= 0.01) & (cand <= 5.0))
     ia, ib = T.overlap(np.array([3.0, 7.0, 9.0]), np.array([9.0, 1.0, 3.0]))
     assert ia.tolist() == [0, 2] and ib.tolist() == [2, 0]
+
+
+def test_acquisition_functions_vs_reference_source():
+    """UCB, EI and overlap against vectors produced by executing the reference's own function
+    source (tune_hyperparms_regression.py:207-230, :253-273, :316-328; oracle/make_golden.py)."""
+    from conftest import golden
+    g = golden("kernels_acq")
+    done, y, params, mu, sd = g["done"], g["y"], g["params"], g["mu"], g["sd"]
+    assert np.array_equal(np.asarray(T.UCB(done, params, mu, sd, 3, 0)), g["ucb"])
+    assert np.array_equal(np.asarray(T.EI(params, mu, sd, done, y, 3, 0)), g["ei"])
+    j = int(np.argmax(mu + 0.001 * sd))
+    assert (T.UCB(np.append(done, params[j, 0]), params, mu, sd, 3, 0) is True) == bool(g["ucb_stop"])
+    ia, ib = T.overlap(g["ov_a"], g["ov_b"])
+    assert np.array_equal(ia, g["ov_ia"]) and np.array_equal(ib, g["ov_ib"])

@@ -572,3 +572,19 @@ def test_co2_bo_loop_runs(ctx):
     for t in traces.values():
         nz = t[t != 0]
         assert np.all(np.diff(nz) >= 0)          # running maximum of the LMLs seen so far
+
+
+def test_thompson_sampling_and_surrogate_vs_reference_source(ctx):
+    """bayesian_opt (:67-101) and TS (:233-250) against the reference's functions executed from
+    source: same np.random stream, posterior through the GPU path."""
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    g = golden("kernels_bo_co2")
+    np.random.seed(21)
+    mu, sd, fp = T.bayesian_opt(g["bo_X"], g["bo_Xs"], g["bo_y"], ctx=ctx)
+    assert np.allclose(mu, g["bo_mu"], rtol=0, atol=1e-9 * np.abs(g["bo_mu"]).max())
+    assert np.allclose(sd, g["bo_sd"], rtol=0, atol=1e-8, equal_nan=True)
+    assert np.allclose(fp, g["bo_fpost"], rtol=0, atol=1e-6 * np.abs(g["bo_fpost"]).max())
+    a = golden("kernels_acq")
+    np.random.seed(22)
+    ts = T.TS(a["done"], a["params"], a["y"], 3, 0, ctx=ctx)
+    assert np.array_equal(np.asarray(ts).reshape(-1), a["ts"].reshape(-1))
