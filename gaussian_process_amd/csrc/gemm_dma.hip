@@ -43,7 +43,6 @@ struct GemmDmaDev {
     const int32_t* row_ncols;
     int row_block_tiles;
     int S, logS, SM, SN, tri, nsuper;
-    int stagger;
     unsigned long long* stamps;   // diagnostic build only (dbg & 16): per-tile phase clocks
     int dbg;   // timing-only ablations (probe instantiation): 1 no DMA in the loop, 2 no barrier/waits, 8 no epilogue
 };
@@ -96,16 +95,6 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
     }
     if (p.row_ncols) {
         if ((int64_t)tj * DMA_TN >= p.row_ncols[ti / p.row_block_tiles]) return;
-    }
-
-    // All tiles of a launch take the same time, so without help every CU reaches its
-    // C read-modify-write at the same moment (one HBM burst per residency wave, idle
-    // memory in between).  The workgroups of the first residency wave start after
-    // 0..15 sixteenths of a tile time; successors inherit the phase.  Speed only.
-    if (p.stagger && blockIdx.x < 256) {
-        const unsigned phase = (blockIdx.x * 0x9E3779B1u) >> 28;              // 0..15
-        const int naps = (int)(phase * (unsigned)p.nchunks) >> 2;             // x 1024 cycles: nch*4096/16 per phase unit
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
     }
 
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
@@ -343,7 +332,6 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     }
     p.dbg = g_gemm_dbg & 0xff;
     p.stamps = g_gemm_stamps;
-    p.stagger = (g_gemm_stagger && (int64_t)p.Tm * p.Tn >= 1024) ? 1 : 0;
     if (g_gemm_dma_waves == 8) {
         if (p.dbg) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, true>), dim3(nblocks), dim3(512), lds, s, p);
         else if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_dma_kernel, dim3(nblocks), dim3(512), lds, s, p);

@@ -44,8 +44,6 @@ struct GemmDev {
     int nsuper;
     const int32_t* row_ncols;
     int row_block_tiles;
-    int stagger;       // start delay of odd-slot first-wave workgroups (s_sleep units), 0 = off
-    int stagger_rule;  // experiment: how the delayed half is chosen
     int dbg;           // timing-only ablations (gpmi_probe_gemm): results are wrong when non-zero
 };
 
@@ -96,22 +94,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     }
     if (p.row_ncols) {
         if ((int64_t)tj * TN >= p.row_ncols[ti / p.row_block_tiles]) return;
-    }
-
-    // The two workgroups that share a CU start together and, sharing each SIMD's
-    // matrix pipe evenly, stay in lockstep: both reach the end-of-step LDS refill
-    // (ds_write, barrier, first fragment reads) at the same time and the pipe
-    // idles.  The workgroup that landed in the odd wave slot of its SIMD therefore
-    // starts half a K step late; successors inherit the offset (a workgroup starts
-    // when a slot frees).  Speed only: results do not depend on placement.
-    if (p.stagger && blockIdx.x < 512) {
-        // HW_REG_HW_ID (id 4), WAVE_ID field [3:0]: hwreg(4, 0, 4)
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);
-        unsigned wslot = __builtin_amdgcn_readfirstlane(slot);
-        if (p.stagger_rule == 1) wslot = blockIdx.x >> 8;        // assume b and b+256 share a CU
-        else if (p.stagger_rule == 2) wslot = blockIdx.x >> 3;   // assume b and b+8 share a CU
-        if (wslot & 1)
-            for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(1);   // x 64 cycles
     }
 
     const int tid = threadIdx.x;
@@ -237,9 +219,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     }
 }
 
-int g_gemm_stagger = 0;    // s_sleep units (x 64 cycles); 0 disables (no measurable effect so far)
 int g_gemm_dbg = 0;
-int g_gemm_stagger_rule = 0;
 
 static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
     p.C = a.C; p.A = a.A; p.B = a.B;
@@ -267,11 +247,7 @@ static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
     }
     p.logS = (p.S == 8) ? 3 : (p.S == 4) ? 2 : (p.S == 2) ? 1 : 0;
     nblocks = ((p.nsuper + 7) / 8) * 8 * p.S * p.S;
-    // stagger only pays when the launch runs several residency waves of long tiles
     p.dbg = g_gemm_dbg;
-    p.stagger_rule = g_gemm_stagger_rule;
-    // half a K step = 32 MFMAs x 64 cycles x 2 waves per SIMD; s_sleep counts 64-cycle units
-    p.stagger = (p.nchunks >= 8 && (int64_t)p.Tm * p.Tn >= 1024) ? g_gemm_stagger : 0;
 }
 
 int g_gemm_use_dma = 1;

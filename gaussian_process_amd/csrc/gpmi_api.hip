@@ -460,7 +460,6 @@ int gpmi_ctx_create(int device, gpmi_ctx** out) {
     if ((env = getenv("GPMI_NB"))) c->nb = std::max<int64_t>(128, atoll(env) / 128 * 128);
     if ((env = getenv("GPMI_LD_PAD"))) c->ld_pad = std::max<int64_t>(0, atoll(env) / 2 * 2);
     if ((env = getenv("GPMI_LOOKAHEAD"))) c->lookahead = atoi(env) ? 1 : 0;
-    if ((env = getenv("GPMI_GEMM_STAGGER"))) g_gemm_stagger = std::min(127, std::max(0, atoi(env)));
     *out = c;
     return GPMI_OK;
 }
@@ -504,11 +503,6 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         g_gemm_dma_waves = (int)value;
     } else if (!strcmp(name, "gemm_dma")) {
         g_gemm_use_dma = value ? 1 : 0;
-    } else if (!strcmp(name, "gemm_stagger_rule")) {
-        g_gemm_stagger_rule = (int)value;
-    } else if (!strcmp(name, "gemm_stagger")) {
-        if (value < 0 || value > 127) return fail_arg("gemm_stagger must be 0..127 (s_sleep units)");
-        g_gemm_stagger = (int)value;
     } else {
         return fail_arg("gpmi_set_option: unknown option");
     }

@@ -39,8 +39,6 @@ extern int g_gemm_dma_waves;  // 4 or 8 waves per workgroup in the LDS-DMA GEMM
 extern int g_gemm_small_tiles;   // 64 x 64 tiles for launches with few tiles
 extern int g_gemm_use_dma;   // 0: never, 1: for launches with >= 256 tiles
 extern int g_gemm_dbg;       // timing-only ablation bits for gpmi_probe_gemm (0 in production)
-extern int g_gemm_stagger_rule;
-extern int g_gemm_stagger;   // tuning switch (GPMI_GEMM_STAGGER / option "gemm_stagger")
 // number of tiles the launch actually computes (for flop accounting)
 double gemm_nt_flops(const GemmArgs& a);
 

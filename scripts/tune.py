@@ -13,8 +13,7 @@ from gaussian_process_amd import GPContext  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-configs = sys.argv[3:] or ["la=0,st=0,nb=512", "la=0,st=1,nb=512", "la=1,st=0,nb=512", "la=1,st=1,nb=512",
-                           "la=1,st=1,nb=256", "la=1,st=1,nb=1024", "la=1,st=1,nb=768"]
+configs = sys.argv[3:] or ["la=0,nb=512", "la=1,nb=512", "la=1,nb=256", "la=1,nb=1024", "la=1,nb=2048"]
 X, y, Xs = O.synthetic_problem(N, 8, n)
 ctx = GPContext(0)
 ctx.set_train(X, y)
@@ -23,7 +22,6 @@ ref = None
 for cfg in configs:
     kv = dict(p.split("=") for p in cfg.split(","))
     ctx.set_option("lookahead", int(kv.get("la", 1)))
-    ctx.set_option("gemm_stagger", int(kv.get("st", 1)))
     ctx.set_option("nb", int(kv.get("nb", 512)))
     if "pad" in kv:
         ctx.set_option("ld_pad", int(kv["pad"]))
