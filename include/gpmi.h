@@ -65,7 +65,11 @@ int gpmi_device_count(int* count);
 /* one context = one GPU (device ordinal) + its streams and workspaces */
 int gpmi_ctx_create(int device, gpmi_ctx** out);
 int gpmi_ctx_destroy(gpmi_ctx* ctx);
-/* tuning knobs (block sizes etc.); unknown names -> GPMI_ERR_BAD_ARG */
+/* tuning knobs; unknown names -> GPMI_ERR_BAD_ARG.
+ * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
+ *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1)
+ * process-wide (kernel selection, for measurements): "gemm_dma" (0/1), "gemm_dma_waves" (4/8),
+ *               "gemm_small_tiles" (0/1), "trsm_wave" (0/1), "rbf_blocks" (persistent blocks of the K build) */
 int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);
 
 /* RBF_kernel(a, b, sigma, l)                         GP_regression.py:8-19

@@ -245,6 +245,11 @@ def bo_and_co2_cases():
     mu, sd = CO2["bayesian_opt"](hp, hq, lmls)                                         # :341 (multi-D branch :83)
     out.update(co2_hp=hp, co2_hq=hq, co2_hp_lml=lmls, co2_bo_mu=mu, co2_bo_sd=sd,
                co2_Khp=CO2["covariance_function"](hp, hq, hp[0]))
+    # the host-side acquisition functions of the CO2 loop (:206-258), executed from source
+    from scipy.stats import norm
+    ACQ = ref_functions("/root/reference/CO2_example.py", ["UBC", "EI"], {"np": np, "norm": norm})
+    out["co2_ubc"] = np.asarray(ACQ["UBC"](hp, hq, mu, sd))
+    out["co2_ei"] = np.asarray(ACQ["EI"](hq, mu, sd, lmls))
     np.savez_compressed(os.path.join(OUT, "kernels_bo_co2.npz"), **out)
 
 

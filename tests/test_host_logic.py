@@ -102,3 +102,21 @@ def test_acquisition_functions_vs_reference_source():
     assert (T.UCB(np.append(done, params[j, 0]), params, mu, sd, 3, 0) is True) == bool(g["ucb_stop"])
     ia, ib = T.overlap(g["ov_a"], g["ov_b"])
     assert np.array_equal(ia, g["ov_ia"]) and np.array_equal(ib, g["ov_ib"])
+
+
+def test_co2_host_functions_vs_reference_source():
+    """init_hyperms, UBC and EI of CO2_example.py (:206-258, :296-306) against vectors produced by
+    executing the reference's own function source."""
+    from conftest import golden
+    from gaussian_process_amd import CO2_example as C2
+    g = golden("kernels_bo_co2")
+    assert np.array_equal(C2.init_hyperms(5, 11), g["co2_hp"])
+    mu, sd = g["co2_bo_mu"], g["co2_bo_sd"]
+    assert np.array_equal(np.asarray(C2.UBC(g["co2_hp"], g["co2_hq"], mu, sd)), g["co2_ubc"])
+    assert np.array_equal(np.asarray(C2.EI(g["co2_hq"], mu, sd, g["co2_hp_lml"])), g["co2_ei"])
+    # candidate sampling: 11 columns inside the reference's [0.3, 1.5] x book window, none already tried
+    import random
+    random.seed(1)
+    cand = C2.random_sample_test_parms(20, g["co2_hp"])
+    assert cand.shape == (20, 11)
+    assert np.all(cand >= 0.3 * C2.HYPERMS_BOOK - 1e-12) and np.all(cand <= 1.5 * C2.HYPERMS_BOOK + 1e-12)
