@@ -588,3 +588,28 @@ def test_thompson_sampling_and_surrogate_vs_reference_source(ctx):
     np.random.seed(22)
     ts = T.TS(a["done"], a["params"], a["y"], 3, 0, ctx=ctx)
     assert np.array_equal(np.asarray(ts).reshape(-1), a["ts"].reshape(-1))
+
+
+def test_non_finite_inputs_behave_like_the_reference(ctx, oracle):
+    """A NaN or Inf in X makes K non-finite; np.linalg.cholesky then raises LinAlgError
+    (GP_regression.py:138) -- so does the device factorisation.  RBF_kernel itself just
+    propagates the NaN (GP_regression.py:18-19); an infinite coordinate gives exp(-inf) = 0
+    against finite points and NaN against itself (inf - inf), as in NumPy."""
+    rng = np.random.default_rng(9)
+    X = rng.uniform(-1, 1, (300, 3))
+    y = np.sin(X.sum(1))
+    for bad in (np.nan, np.inf):
+        Xb = X.copy()
+        Xb[137, 1] = bad
+        with np.errstate(invalid="ignore"):
+            ref = oracle.RBF_kernel(Xb, Xb, 1.0, 1.5)
+        K = ctx.rbf(Xb, Xb, 1.0, 1.5)
+        assert np.array_equal(np.isnan(K), np.isnan(ref))
+        ok = ~np.isnan(ref)
+        assert np.allclose(K[ok], ref[ok], rtol=K_RTOL, atol=0)
+        with pytest.raises(np.linalg.LinAlgError):
+            ctx.fit(Xb, y, 1.0, 1.5, 5e-4)
+    yb = y.copy()
+    yb[5] = np.nan                       # NaN targets do not stop the factorisation: the LML is NaN, as in NumPy
+    assert np.isnan(ctx.fit(X, yb, 1.0, 1.5, 5e-4))
+    assert np.isfinite(ctx.fit(X, y, 1.0, 1.5, 5e-4))
