@@ -17,10 +17,10 @@
 //     publishes stage c+1 (every wave has waited for its own DMA pieces) and retires
 //     the last reads of the stage that the next DMA overwrites.
 //
-// Order per K step c (per wave):
-//   issue DMA(c+2) -> stage (c+2)%3 | 16 MFMA on F0 | read F1 <- stage c%3, k-pairs 4..7
-//   16 MFMA on F0 | s_waitcnt vmcnt(pieces of c+2), lgkmcnt(0) | s_barrier
-//   read F0 <- stage (c+1)%3, k-pairs 0..3 | 32 MFMA on F1
+// Order per K step c (per wave), MFMAs in four quarters (F0.x, F0.y, F1.x, F1.y):
+//   F0.x + read F1 <- stage c%3, k-pairs 4..7 | F0.y + issue DMA(c+2) -> stage (c+2)%3
+//   s_waitcnt vmcnt(pieces of c+2 may fly), lgkmcnt(0) | s_barrier
+//   F1.x + read F0 <- stage (c+1)%3, k-pairs 0..3 | F1.y
 #include "gpmi_internal.h"
 
 namespace gpmi {
@@ -182,29 +182,34 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
 
     // Every non-MFMA instruction of the step sits alone behind two MFMAs (128 matrix-pipe
     // cycles of cover for an LDS-DMA issue of ~60 cycles or a ds_read of ~16):
-    //   quarter 0 (F0 .x): the DMA wave-instructions of step c+2
-    //   quarter 1 (F0 .y): the fragment reads F1 <- stage c, k-pairs 4..7
+    //   quarter 0 (F0 .x): the fragment reads F1 <- stage c, k-pairs 4..7
+    //   quarter 1 (F0 .y): the DMA wave-instructions of step c+2
     //   wait + barrier (publishes stage c+1, retires the reads of the stage DMA(c+3) overwrites)
-    //   quarter 2 (F1 .x): (rest of the fragment reads when MI = 2)
-    //   quarter 3 (F1 .y): the fragment reads F0 <- stage c+1, k-pairs 0..3
+    //   quarter 2 (F1 .x): the fragment reads F0 <- stage c+1, k-pairs 0..3
+    //   quarter 3 (F1 .y): matrix pipe only
+    // so every fragment is read a full quarter step (>= 512 matrix-pipe cycles) before its first use
+    // and neither the barrier's lgkmcnt(0) nor the next step's first MFMA waits on LDS latency.
     for (int c = 0; c < nch; ++c) {
         const bool more2 = (c + 2 < nch) && !(dbg & 1);
         const bool more1 = (c + 1 < nch);
+        // quarter 0 (F0 .x): fragment reads F1 <- stage c, k-pairs 4..7 (a full quarter ahead of their use)
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             GPMI_MFMA_X(fa0, fb0, 2 * q);
             GPMI_MFMA_X(fa0, fb0, 2 * q + 1);
             GPMI_FENCE();
-            if (more2 && q < DPW) issue_dma_one(c + 2, q);
+            if (q < NFR) read_one(c, 1, q, fa1, fb1);
+            if (NSLOT < NFR && q + NSLOT < NFR) read_one(c, 1, q + NSLOT, fa1, fb1);
             GPMI_FENCE();
         }
+        // quarter 1 (F0 .y): the DMA wave-instructions of step c+2
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
             GPMI_MFMA_Y(fa0, fb0, 2 * q);
             GPMI_MFMA_Y(fa0, fb0, 2 * q + 1);
             GPMI_FENCE();
-            if (q < NFR) read_one(c, 1, q, fa1, fb1);
-            if (NSLOT < NFR && q + NSLOT < NFR) read_one(c, 1, q + NSLOT, fa1, fb1);
+            if (more2 && q < DPW) issue_dma_one(c + 2, q);
+            if (more2 && NSLOT < DPW && q + NSLOT < DPW) issue_dma_one(c + 2, q + NSLOT);
             GPMI_FENCE();
         }
         if (!(dbg & 2)) {
@@ -217,18 +222,20 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
             __builtin_amdgcn_s_barrier();
         }
         GPMI_FENCE();
-#pragma unroll
-        for (int t = 0; t < NT; ++t) GPMI_MFMA_X(fa1, fb1, t);
-        GPMI_FENCE();
+        // quarter 2 (F1 .x): fragment reads F0 <- stage c+1, k-pairs 0..3 (published by the barrier above)
 #pragma unroll
         for (int q = 0; q < NSLOT; ++q) {
-            GPMI_MFMA_Y(fa1, fb1, 2 * q);
-            GPMI_MFMA_Y(fa1, fb1, 2 * q + 1);
+            GPMI_MFMA_X(fa1, fb1, 2 * q);
+            GPMI_MFMA_X(fa1, fb1, 2 * q + 1);
             GPMI_FENCE();
             if (more1 && q < NFR) read_one(c + 1, 0, q, fa0, fb0);
             if (more1 && NSLOT < NFR && q + NSLOT < NFR) read_one(c + 1, 0, q + NSLOT, fa0, fb0);
             GPMI_FENCE();
         }
+        // quarter 3 (F1 .y): matrix pipe only
+#pragma unroll
+        for (int t = 0; t < NT; ++t) GPMI_MFMA_Y(fa1, fb1, t);
+        GPMI_FENCE();
     }
 #undef GPMI_MFMA_X
 #undef GPMI_MFMA_Y
