@@ -18,6 +18,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC (RCCL / cross-process device memory)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_FP64_MFMA_TFLOPS = 78.6     # vendor dense fp64 matrix peak, MI355X
 PEAK_HBM_GBPS = 8000.0
