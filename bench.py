@@ -192,7 +192,7 @@ def main():
             launches = stage.get("trail_launches", 0.0) / k
             ach = trail_flops / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else 0.0
             traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01c_roofline_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01d_roofline_traffic.json")
             if os.path.exists(tpath) and N == 65536 and n == 4096:
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same
                 # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/rocpd_extract.py traffic)
