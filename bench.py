@@ -118,7 +118,7 @@ def main():
             dist.init_process_group(backend)
         from gaussian_process_amd.dist import DistGP
         gp = DistGP(local_rank, nb=int(os.environ.get("GPMI_DIST_NB", "512")),
-                    lookahead=os.environ.get("GPMI_DIST_LOOKAHEAD", "1") == "1")
+                    lookahead=int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2")))
         gp.set_train(X, y)
         gp.set_test(Xs)
 

@@ -117,7 +117,7 @@ class HipBlockOps:
 class DistGP:
     """Row-block cyclic GP fit / predict over the ranks of `group` (default: WORLD)."""
 
-    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=True):
+    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=2):
         if not dist.is_initialized():
             raise RuntimeError("DistGP needs torch.distributed (init_process_group) -- one rank per GPU")
         if nb <= 0 or nb % 128:
@@ -129,7 +129,11 @@ class DistGP:
         self.dev = self.ops.device
         self.NB = int(nb)
         self.ld_pad = int(ld_pad) // 2 * 2
-        self.lookahead = bool(lookahead)
+        # 0: none; 1: panel k+1 (diagonal block, broadcast, solves, all-gather) behind the trailing
+        # update of step k; 2: additionally "critical path first" -- the owner of diagonal block k+1
+        # solves and updates its own block row and factors the block on a third stream before the
+        # rest of panel k is gathered, so the latency-bound potrf leaves the collective chain
+        self.lookahead = int(lookahead)
         self.have_factor = False
         self.have_test = False
         self.stage_ms = {}
@@ -176,6 +180,7 @@ class DistGP:
         cmax = max(self._nblocks(r) for r in range(G))
         self.send = self._tensor(max(cmax, 1) * NB, NB)
         self.recv = self._tensor(G * max(cmax, 1) * NB, NB)
+        self.Lk = [self.Lkk, self._tensor(NB, NB)]
         self.Pbuf = [self._tensor(max(self.T - 1, 1) * NB, NB) for _ in range(2 if self.lookahead else 1)] \
             if G > 1 else [None, None]
         self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
@@ -212,6 +217,16 @@ class DistGP:
         self.rowmapB = torch.tensor(flat, dtype=torch.int32, device=self.dev)
         self.rowmapB_off = offs
         self.rowmapB_len = [len(t) for t in tabs]
+        # critical-path-first schedule: the diagonal block of block row k+2 is updated ahead of part (b)
+        # (it is the next but one to be factored), so its bands update nothing in (b)
+        flatC = []
+        for k, t in enumerate(tabs):
+            t = list(t)
+            ls1 = self._lstart(k + 1)
+            if ls1 < self.nloc and self.my_blocks[ls1] == k + 2:
+                t[:bands] = [0] * bands
+            flatC += t
+        self.rowmapC = torch.tensor(flatC or [0], dtype=torch.int32, device=self.dev)
         self.have_factor = False
         self.have_test = False
 
@@ -228,6 +243,44 @@ class DistGP:
             lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
             self._side_stream = torch.cuda.Stream(device=self.dev, priority=hi)
         return torch.cuda.stream(self._side_stream)
+
+    def _named_stream(self, name):
+        if not self._cuda():
+            return None
+        streams = self.__dict__.setdefault("_streams", {})
+        if name not in streams:
+            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+            streams[name] = torch.cuda.Stream(device=self.dev, priority=hi)
+        return streams[name]
+
+    def _on(self, name):
+        """context manager: run on the named auxiliary stream ('side', 'crit'); no-op on CPU"""
+        import contextlib
+        if not self._cuda():
+            return contextlib.nullcontext()
+        if name == "side":
+            return self._side()
+        return torch.cuda.stream(self._named_stream(name))
+
+    def _stream_of(self, name):
+        if name == "main":
+            return torch.cuda.current_stream(self.dev)
+        if name == "side":
+            with self._side():
+                return torch.cuda.current_stream(self.dev)
+        return self._named_stream(name)
+
+    def _record(self, name):
+        """event after everything queued so far on the named stream (None on CPU)"""
+        if not self._cuda():
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self._stream_of(name))
+        return ev
+
+    def _wait(self, name, ev):
+        if ev is not None:
+            self._stream_of(name).wait_event(ev)
 
     def _order(self, first_is_side):
         """make the other stream wait for everything queued so far on the first one"""
@@ -281,6 +334,105 @@ class DistGP:
                 first = r + self._lstart(k, r) * G        # global index of r's first block below k
                 Pv[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
 
+    def _gather_panel(self, k, P, r0):
+        """all-gather of block column k below the diagonal (every rank's solved rows, starting at local
+        row r0) into P in natural block order; runs on the current stream"""
+        NB, G, A = self.NB, self.G, self.A
+        c0 = k * NB
+        cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
+        cmax = max(cnts)
+        cnt = cnts[self.rank]
+        nbelow = self.T - k - 1
+        send = self.send[:cmax * NB]
+        if cnt:
+            send[:cnt * NB].copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
+        recv = self.recv[:G * cmax * NB]
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        Pv = P[:nbelow * NB].view(nbelow, NB, NB)
+        R = recv.view(G, cmax, NB, NB)
+        for r in range(G):
+            if cnts[r]:
+                first = r + self._lstart(k, r) * G
+                Pv[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
+
+    def _factor_critical_path_first(self):
+        """Right-looking sweep with the diagonal chain decoupled from the panel chain.
+
+        Per step k, three streams:
+          crit  owner of block k+1 only: its block (k+1, k) <- block * L_kk^-T, the diagonal block
+                (k+1, k+1) -= that block times its transpose, Cholesky of the diagonal block;
+                then (all ranks) the broadcast of L_(k+1)(k+1)
+          side  every rank: its other rows of block column k <- rows * L_kk^-T, all-gather of the column
+          main  (a) block column k+1 of the rows below block k+1, (b) the remaining columns
+        Dependencies across streams are events; every rank issues the collectives in the same
+        order (broadcast k, all-gather k, broadcast k+1, ...)."""
+        ops, NB, G, A, T = self.ops, self.NB, self.G, self.A, self.T
+        Lk = self.Lk
+        ev_a = self._record("main")                      # the K build
+        self._wait("crit", ev_a)
+        with self._on("crit"):
+            if self.rank == 0 % G:
+                diag = A[0:NB, 0:NB]
+                ops.potrf_block(diag, 0, self.info)
+                Lk[0].copy_(diag)
+            if G > 1:
+                dist.broadcast(Lk[0], src=self._src(0), group=self.group)
+        ev_bcast = self._record("crit")
+        for k in range(T):
+            Lcur = Lk[k % 2]
+            c0, c1 = k * NB, (k + 1) * NB
+            ls = self._lstart(k)                         # my first local block below k
+            own_next = (k + 1 < T) and (self.rank == (k + 1) % G)
+            ev_row = None
+            if own_next:                                 # block k+1 is my local block `ls`
+                self._wait("crit", ev_a)                 # its columns <= k+1 are final up to step k-1
+                with self._on("crit"):
+                    blk = A[ls * NB:(ls + 1) * NB, c0:c0 + NB]
+                    ops.trsm_block(Lcur, blk)
+                    ev_row = self._record("crit")
+                    dk = A[ls * NB:(ls + 1) * NB, c1:c1 + NB]
+                    ops.gemm_nt(dk, blk, blk)
+                    ops.potrf_block(dk, c1, self.info)
+                    Lk[(k + 1) % 2].copy_(dk)
+            self._wait("side", ev_bcast)                 # L_kk has arrived
+            self._wait("side", ev_a)                     # block column k carries every update before step k
+            with self._on("side"):
+                r_rest = (ls + 1) * NB if own_next else ls * NB
+                m = self.rows - r_rest
+                if m > 0:
+                    ops.trsm_block(Lcur, A[r_rest:r_rest + m, c0:c0 + NB])
+                if k < T - 1 and G > 1:
+                    self._wait("side", ev_row)
+                    self._gather_panel(k, self.Pbuf[k % 2], ls * NB)
+            ev_panel = self._record("side")
+            if k == T - 1:
+                self._wait("main", ev_panel)
+                break
+            with self._on("crit"):                       # queued behind the owner's potrf on this stream
+                if G > 1:
+                    dist.broadcast(Lk[(k + 1) % 2], src=self._src((k + 1) % G), group=self.group)
+            ev_bcast = self._record("crit")
+            self._wait("main", ev_panel)
+            if G == 1:
+                self._wait("main", ev_row)
+            P = self._panel_view(k, self.Pbuf[k % 2])
+            r1 = self._lstart(k + 1) * NB                # my rows of blocks > k+1 (and the y rows)
+            m1 = self.rows - r1
+            if m1 > 0:                                   # (a) block column k+1 below its diagonal block
+                ops.gemm_nt(A[r1:r1 + m1, c1:c1 + NB], A[r1:r1 + m1, c0:c0 + NB], P[:NB])
+            ls1 = self._lstart(k + 1)
+            if k + 2 < T and ls1 < self.nloc and self.my_blocks[ls1] == k + 2:
+                # (a2) the diagonal block of my block row k+2: everything the next critical step reads
+                rows = slice(ls1 * NB, (ls1 + 1) * NB)
+                ops.gemm_nt(A[rows, c1 + NB:c1 + 2 * NB], A[rows, c0:c0 + NB], P[NB:2 * NB])
+            ev_a = self._record("main")
+            if k + 2 < T and m1 > 0:                     # (b) the remaining columns
+                off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
+                ops.gemm_nt_rowmap(A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], P[NB:],
+                                   self.rowmapC[off:off + ln], 128)
+        self._wait("main", ev_bcast)
+        self._wait("main", self._record("crit"))
+
     def _panel_view(self, k, P):
         """the panel column below block k in natural order (blocks k+1 ..)"""
         nbelow = self.T - k - 1
@@ -294,10 +446,11 @@ class DistGP:
         (tune_hyperparms_regression.py:312) on every rank.  Raises LinAlgError on every
         rank if a pivot is not positive.
 
-        With lookahead (default) the trailing update of step k is split: (a) block column
-        k+1 first, then the side stream runs the whole panel step k+1 (diagonal block,
-        broadcast, solves, all-gather) while (b) the remaining columns update on the main
-        stream -- collectives and the latency-bound panel kernels hide behind the MFMA work."""
+        Lookahead level 1: the trailing update of step k is split: (a) block column k+1 first,
+        then the side stream runs the whole panel step k+1 (diagonal block, broadcast, solves,
+        all-gather) while (b) the remaining columns update on the main stream -- collectives and
+        the latency-bound panel kernels hide behind the MFMA work.  Level 2 (default): see
+        _factor_critical_path_first."""
         import time
         t_begin = time.perf_counter()
         ops, NB, G, A = self.ops, self.NB, self.G, self.A
@@ -312,7 +465,9 @@ class DistGP:
             A[self.yrow:self.yrow + YB, :self.Np].zero_()
             A[self.yrow, :self.N].copy_(self.y)
         T = self.T
-        if not self.lookahead:
+        if self.lookahead >= 2:
+            self._factor_critical_path_first()
+        elif not self.lookahead:
             for k in range(T):
                 self._panel_step(k, self.Pbuf[0])
                 if k == T - 1:

@@ -13,8 +13,8 @@ n = 4096
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 X, y, Xs = O.synthetic_problem(N, 8, n)
-for nb in (512, 1024):
-    for la in (True, False):
+for nb, la in [(int(a.split(',')[0]), int(a.split(',')[1])) for a in (sys.argv[2:] or ['512,2', '512,1', '512,0', '1024,2', '1024,1', '1024,0'])]:
+    if True:
         gp = DistGP(0, nb=nb, lookahead=la)
         gp.set_train(X, y); gp.set_test(Xs)
         best = None

@@ -22,10 +22,10 @@ def main():
     if device == "cpu":
         torch.set_num_threads(2)
         from numpy_block_ops import NumpyBlockOps
-        gp = DistGP(nb=nb, ops=NumpyBlockOps(), lookahead=os.environ.get("DISTGP_LOOKAHEAD", "1") == "1")
+        gp = DistGP(nb=nb, ops=NumpyBlockOps(), lookahead=int(os.environ.get("DISTGP_LOOKAHEAD", "1")))
     else:
         torch.cuda.set_device(0)           # all ranks share the one GPU of the test box
-        gp = DistGP(0, nb=nb, lookahead=os.environ.get("DISTGP_LOOKAHEAD", "1") == "1")
+        gp = DistGP(0, nb=nb, lookahead=int(os.environ.get("DISTGP_LOOKAHEAD", "1")))
     X, y, Xs = O.synthetic_problem(N, d, n, seed=77)
     lml = gp.fit(X, y, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
     mu, var = gp.predict(Xs, want_sd=False)

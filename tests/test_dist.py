@@ -76,6 +76,14 @@ def test_three_ranks_gloo_cpu_uneven_blocks(oracle, tmp_path):
     _check(res, oracle, 520, 2, 33)
 
 
+@pytest.mark.parametrize("world,N,d,n,nb", [(2, 700, 3, 50, 128), (3, 520, 2, 33, 128), (2, 300, 8, 140, 256),
+                                            (3, 1100, 4, 20, 128)])
+def test_critical_path_first_schedule_gloo_cpu(oracle, tmp_path, world, N, d, n, nb):
+    """lookahead level 2: the diagonal chain on its own stream (same results, different order of launches)."""
+    res = _run(world, "gloo", "cpu", tmp_path, N, d, n, nb, lookahead=2)
+    _check(res, oracle, N, d, n)
+
+
 def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
     res = _run(2, "gloo", "cpu", tmp_path, 640, 4, 40, 128, lookahead=0)
     _check(res, oracle, 640, 4, 40)
@@ -85,7 +93,9 @@ def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
 @pytest.mark.parametrize("world,N,d,n,nb,la", [(2, 1500, 8, 200, 256, 1), (3, 2100, 8, 130, 128, 1),
                                                 (2, 4096, 8, 512, 512, 1), (2, 1500, 8, 200, 256, 0),
                                                 (1, 1300, 8, 100, 256, 1),
-                                                (2, 6144, 8, 128, 256, 1)])   # large enough for the LDS-DMA GEMM + row map
+                                                (2, 6144, 8, 128, 256, 1),    # large enough for the LDS-DMA GEMM + row map
+                                                (1, 1300, 8, 100, 256, 2), (2, 1500, 8, 200, 256, 2),
+                                                (3, 2100, 8, 130, 128, 2), (2, 6144, 8, 128, 256, 2)])
 def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
     res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb, lookahead=la)
     _check(res, oracle, N, d, n)
