@@ -67,7 +67,8 @@ int gpmi_ctx_create(int device, gpmi_ctx** out);
 int gpmi_ctx_destroy(gpmi_ctx* ctx);
 /* tuning knobs; unknown names -> GPMI_ERR_BAD_ARG.
  * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
- *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1)
+ *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "ramp" (0/1, default 0: block widths ramp up/down
+ *               at the ends of the sweep when "nb" is automatic)
  * process-wide (kernel selection, for measurements): "gemm_dma" (0/1), "gemm_dma_waves" (4/8),
  *               "gemm_small_tiles" (0/1), "trsm_wave" (0/1), "rbf_blocks" (persistent blocks of the K build) */
 int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);

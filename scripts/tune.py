@@ -23,6 +23,7 @@ for cfg in configs:
     kv = dict(p.split("=") for p in cfg.split(","))
     ctx.set_option("lookahead", int(kv.get("la", 1)))
     ctx.set_option("nb", int(kv.get("nb", 512)))
+    ctx.set_option("ramp", int(kv.get("ramp", 0)))
     if "pad" in kv:
         ctx.set_option("ld_pad", int(kv["pad"]))
     best = None
