@@ -67,7 +67,8 @@ int gpmi_ctx_create(int device, gpmi_ctx** out);
 int gpmi_ctx_destroy(gpmi_ctx* ctx);
 /* tuning knobs; unknown names -> GPMI_ERR_BAD_ARG.
  * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
- *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "ramp" (0/1, default 0: block widths ramp up/down
+ *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "lanes" (factorisations in flight in
+ *               gpmi_lml_batch, 0 = by size), "ramp" (0/1, default 0: block widths ramp up/down
  *               at the ends of the sweep when "nb" is automatic)
  * process-wide (kernel selection, for measurements): "gemm_dma" (0/1), "gemm_dma_waves" (4/8),
  *               "gemm_small_tiles" (0/1), "trsm_wave" (0/1), "rbf_blocks" (persistent blocks of the K build) */
@@ -161,7 +162,11 @@ int gpmi_grad_trace(gpmi_ctx* ctx, const double* a, const double* b, int64_t N, 
  *                    tune_hyperparms_regression.py:292-313 called in the loops at :368-369,:385-386
  * triples: T x 3 = (ell, sigma_f, noise_var).  lml_out: T doubles (NaN where the
  * factorisation failed), status_out: T ints (GPMI_OK / GPMI_ERR_NOT_PD), may be
- * NULL.  Uses the training set of gpmi_set_train. */
+ * NULL.  Uses the training set of gpmi_set_train.  Up to "lanes" factorisations are in flight at once
+ * (extra lanes = internal contexts with their own streams and workspaces; by size: 2 up to N = 32768,
+ * else 1): the latency-bound panel steps of one fill with the MFMA work of another.
+ * Each triple is factored by the same launches whatever the lane count, so the results are bitwise
+ * independent of it; the factor left resident is that of the last triple. */
 int gpmi_lml_batch(gpmi_ctx* ctx, const double* triples, int64_t T, double* lml_out,
                    int* status_out);
 

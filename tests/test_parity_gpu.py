@@ -613,3 +613,40 @@ def test_non_finite_inputs_behave_like_the_reference(ctx, oracle):
     yb[5] = np.nan                       # NaN targets do not stop the factorisation: the LML is NaN, as in NumPy
     assert np.isnan(ctx.fit(X, yb, 1.0, 1.5, 5e-4))
     assert np.isfinite(ctx.fit(X, y, 1.0, 1.5, 5e-4))
+
+
+@pytest.mark.parametrize("N", [300, 3000])
+def test_lml_batch_lanes_are_bitwise_equivalent(oracle, N):
+    """gpmi_lml_batch keeps several factorisations in flight (option "lanes"); every triple goes
+    through the same launches whatever the lane count, so the numbers do not depend on it, the
+    not-PD status lands on the right triple, the factor left resident is the last triple's and
+    the batch survives a change of training set and of covariance function."""
+    from gaussian_process_amd import GPContext
+    c = GPContext(0)
+    X, y, Xs = oracle.synthetic_problem(N, 8, 40)
+    c.set_train(X, y)
+    triples = np.array([[1.0 + 0.3 * t, 0.8 + 0.1 * (t % 3), 5e-4] for t in range(7)])
+    triples[3, 2] = -0.9                                       # not positive definite
+    res = {}
+    for lanes in (1, 2, 4, 0):
+        c.set_option("lanes", lanes)
+        res[lanes] = c.lml_batch(triples)
+        mu, sd = c.predict(Xs)                                 # the resident factor belongs to triples[-1]
+        ref = oracle.posterior(X, Xs, y, triples[-1, 1], triples[-1, 0], triples[-1, 2])
+        assert np.allclose(mu, ref["mu"], rtol=0, atol=MU_ATOL)
+    for lanes in (2, 4, 0):
+        assert np.array_equal(res[lanes][0], res[1][0], equal_nan=True)
+        assert np.array_equal(res[lanes][1], res[1][1])
+    assert res[1][1].tolist() == [0, 0, 0, 1, 0, 0, 0] and np.isnan(res[1][0][3])
+    t = 5
+    want = oracle.compute_mar_likelihood(X, None, y, triples[t, 1], triples[t, 0], s=triples[t, 2])
+    assert abs(res[0][0][t] - want) <= LML_RTOL * abs(want)
+    # new training set: the lanes pick it up
+    X2, y2, _ = oracle.synthetic_problem(N + 64, 8, 4, seed=5)
+    c.set_train(X2, y2)
+    c.set_option("lanes", 3)
+    l3, _ = c.lml_batch(triples[:3])
+    for t in range(3):
+        want = oracle.compute_mar_likelihood(X2, None, y2, triples[t, 1], triples[t, 0], s=triples[t, 2])
+        assert abs(l3[t] - want) <= LML_RTOL * abs(want)
+    c.close()
