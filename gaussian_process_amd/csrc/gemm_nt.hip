@@ -19,6 +19,8 @@
 // Tile order: 1-D grid; block b runs on XCD group b % 8 (round-robin dispatch,
 // a speed assumption only), and each group walks whole S x S super-tiles so
 // that the blocks resident on one XCD share A/B row slabs in its L2.
+#include <algorithm>
+
 #include "gpmi_internal.h"
 
 namespace gpmi {
@@ -306,6 +308,27 @@ double gemm_nt_flops(const GemmArgs& a) {
         tiles += cnt < Tn ? cnt : Tn;
     }
     return 2.0 * (double)tiles * 128.0 * TN * (double)a.K;
+}
+
+// Algorithmic flops of a lower-mode update: 2 K per element on or below the diagonal
+// (col <= row + diag_off) of the first `real_rows` rows -- what the Cholesky needs, as opposed to
+// what the tiles compute (whole diagonal tiles, padding rows).
+double gemm_nt_algorithmic_flops(const GemmArgs& a, int64_t real_rows) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0.;
+    const int64_t rows = std::min<int64_t>(a.M, real_rows);
+    if (!a.lower) return 2.0 * (double)rows * (double)a.N * (double)a.K;
+    // row r reaches min(N, r + diag_off + 1) columns
+    double elems = 0.;
+    const int64_t r_full = std::max<int64_t>(0, a.N - 1 - a.diag_off);        // first row that reaches all N columns
+    const int64_t r_first = std::max<int64_t>(0, -a.diag_off);              // first row that reaches column 0
+    const int64_t tri_end = std::min(rows, r_full);
+    if (tri_end > r_first) {
+        const double n = (double)(tri_end - r_first);
+        const double first = (double)(r_first + a.diag_off + 1);
+        elems += n * first + n * (n - 1) / 2.0;
+    }
+    if (rows > r_full) elems += (double)(rows - std::max(r_full, (int64_t)0)) * (double)a.N;
+    return 2.0 * elems * (double)a.K;
 }
 
 }  // namespace gpmi

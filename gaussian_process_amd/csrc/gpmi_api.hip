@@ -311,7 +311,8 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         c->span_end(sp, sm);
         if (account && dma) {
             c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
-            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_flops(g);
+            // algorithmic: the lower triangle of the real rows plus the one row that carries y
+            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_algorithmic_flops(g, ncols - r0 + 1);
         }
         return er;
     };

@@ -30,7 +30,8 @@ struct GemmArgs {
     int role = 0;   // 1: Cholesky trailing update (launched under its own kernel symbol)
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
-bool gemm_nt_routes_dma(const GemmArgs& a);   // true when launch_gemm_nt hands this launch to the LDS-DMA kernel
+bool gemm_nt_routes_dma(const GemmArgs& a);
+double gemm_nt_algorithmic_flops(const GemmArgs& a, int64_t real_rows);   // 2K per needed element (lower: on/below the diagonal)   // true when launch_gemm_nt hands this launch to the LDS-DMA kernel
 // gemm_dma.hip: one-workgroup-per-CU LDS-DMA variant (mode 0, N % 128 == 0)
 bool gemm_dma_eligible(const GemmArgs& a);
 hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);

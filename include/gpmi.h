@@ -50,7 +50,7 @@ enum {
     GPMI_T_ALPHA = 8,     /* a5: backward solve L^T alpha = m              */
     GPMI_T_POSTCHOL = 9,  /* f1: v^T v, K** + jitter*I - v^T v, its Cholesky */
     GPMI_T_TRAIL_LAUNCHES = 10, /* number of trailing-update launches in last fit */
-    GPMI_T_TRAIL_FLOPS = 11,    /* algorithmic flops of those launches (2*M*N*K over computed tiles) */
+    GPMI_T_TRAIL_FLOPS = 11,    /* algorithmic flops of those launches: 2K per element on or below the diagonal, real rows + the y row */
     GPMI_T_GRAD = 12,     /* f2: L^-T, K_y^-1 and the fused gradient trace */
     GPMI_T_COUNT = 16
 };
