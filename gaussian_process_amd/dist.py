@@ -16,6 +16,9 @@ Right-looking step k (block column k):
   every rank: its rows below k  <-  rows * L_kk^-T        [gpmi_dev_trsm_block]
   all-gather of the panel column (each rank's rows)       [RCCL all_gather]
   every rank: trailing update of its own rows, one launch  [gpmi_dev_gemm_nt_rowmap]
+With lookahead (DistGP(lookahead=...)) the update is split so that block column k+1 is ready
+first and the next panel step overlaps the rest of the update; level 2 (default) also takes
+the Cholesky of diagonal block k+1 off the collective chain (_factor_critical_path_first).
 Predict: v^T = K_s^T L^-T with the COLUMN blocks of v^T distributed like the row
 blocks of L; per step the owner solves its block, broadcasts it, and every rank
 updates its own column blocks; mean / variance are ordered sums of per-rank partial
