@@ -7,6 +7,9 @@ sys.path.insert(0, ROOT)
 import torch
 from gaussian_process_amd.dist import HipBlockOps
 ops = HipBlockOps(0)
+if len(sys.argv) > 1:          # panel_rate.py <trsm_wave option: 0 lane per row, 1 wave per row up to 16384 rows>
+    from gaussian_process_amd import GPContext
+    GPContext(0).set_option("trsm_wave", int(sys.argv[1]))
 dev = torch.device("cuda", 0)
 info = torch.full((1,), (1 << 63) - 1, dtype=torch.int64, device=dev)
 
@@ -22,7 +25,7 @@ def timeit(fn, reps=20):
 
 
 rng = np.random.default_rng(0)
-for nb in (128, 256, 512, 1024):
+for nb in (128, 512):
     B = rng.standard_normal((nb, nb)); S = B @ B.T + nb * np.eye(nb)
     A0 = torch.from_numpy(S).to(dev); A = torch.empty(nb, nb + 32, dtype=torch.float64, device=dev)
     def f():
@@ -32,7 +35,7 @@ for nb in (128, 256, 512, 1024):
     t = timeit(f) - timeit(g)
     print("potrf_block nb=%4d: %7.1f us  (%.2f TFLOP/s)" % (nb, t, nb ** 3 / 3 / t / 1e6), flush=True)
     L = torch.from_numpy(np.linalg.cholesky(S)).to(dev)
-    for m in (1024, 4096, 16384, 65536):
+    for m in (512, 4096, 8192, 16384, 65536):
         X = torch.randn(m, nb + 32, dtype=torch.float64, device=dev)
         t = timeit(lambda: ops.trsm_block(L, X[:, :nb]))
         print("   trsm_block m=%6d nb=%4d: %7.1f us  (%.2f TFLOP/s)" % (m, nb, t, m * nb * nb / t / 1e6), flush=True)
