@@ -71,10 +71,12 @@ def _select_kernel(ctx, kernel_choice, parameter, sigma):
 
 
 def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIGMA_F,
-               noise_var=NOISE_VAR, jitter=POST_JITTER, ctx=None):
+               noise_var=NOISE_VAR, jitter=POST_JITTER, return_lml=False, ctx=None):
     """GP posterior at the test points, reference GP_regression.py:109-156.
 
-    :return: (mu_post (n,), stand_devi (n,), f_post_fun (n, num_fun))
+    :return: (mu_post (n,), stand_devi (n,), f_post_fun (n, num_fun)); with return_lml=True a
+             fourth element, the log marginal likelihood of the fit (tune_hyperparms_regression.py:312
+             -- not the discarded expression at GP_regression.py:151, which lacks the log)
     Raises numpy.linalg.LinAlgError where the reference's np.linalg.cholesky
     would (K + sI at :138, posterior covariance at :154).  The normals of :155
     are drawn on the host from np.random in the reference's order.
@@ -82,13 +84,15 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
     ctx = ctx or default_context()
     try:
         sg, ll = _select_kernel(ctx, kernel_choice, l, sigma)  # :125-136
-        ctx.fit(X_train, y_train, sg, ll, noise_var)          # :126,138-140
+        lml = ctx.fit(X_train, y_train, sg, ll, noise_var)    # :126,138-140
         mu_post, stand_devi = ctx.predict(X_test, want_sd=True)  # :127,143-148
         n = mu_post.shape[0]
         L_ = ctx.post_chol(jitter)                            # :154
     finally:
         ctx.set_kernel('rbf')
     f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(n, num_fun)))  # :155
+    if return_lml:
+        return mu_post, stand_devi, f_post_fun, np.float64(lml)
     return mu_post, stand_devi, f_post_fun
 
 

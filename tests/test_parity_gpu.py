@@ -110,6 +110,15 @@ def test_dropin_prediction_cfg1(seed):
     assert np.max(np.abs(mu - f(Xs))) < 0.05              # it still regresses the sine
 
 
+def test_dropin_prediction_return_lml():
+    from gaussian_process_amd import GP_regression as G
+    g = golden("d8_box1_N256")
+    np.random.seed(3)
+    out = G.prediction(g["X"], g["Xs"], g["y"], 'rbf', float(g["ell"]), 3, return_lml=True)
+    assert len(out) == 4 and abs(out[3] - float(g["lml"])) <= LML_RTOL * abs(float(g["lml"]))
+    assert np.allclose(out[0], g["mu"], atol=MU_ATOL)
+
+
 @pytest.mark.parametrize("name", golden_names("d"))
 def test_dropin_compute_mar_likelihood(name):
     from gaussian_process_amd import GP_regression as G
