@@ -1,0 +1,114 @@
+// Device-pointer block primitives of the C-ABI (gpmi_dev_*): the building blocks the multi-GPU
+// driver (gaussian_process_amd/dist.py) chains on its own streams.  No context, no host copies.
+#include "gpmi_ctx.h"
+
+using namespace gpmi;
+
+extern "C" {
+
+// ---- device-pointer block primitives (multi-GPU driver) -------------------------
+int gpmi_dev_rbf_rows(void* stream, const double* X_dev, int64_t N, int64_t d, int64_t row0,
+                      int64_t nrows, int64_t ncols, double sigma, double ell, double noise_var,
+                      double* out_dev, int64_t ld) {
+    if (!X_dev || !out_dev) return fail_arg("gpmi_dev_rbf_rows: null pointer");
+    if (nrows % TILE || ncols % TILE || row0 % TILE || ld < ncols || ld % 2)
+        return fail_arg("gpmi_dev_rbf_rows: sizes must be multiples of 128");
+    RbfArgs r;
+    r.A = r.B = X_dev; r.nA = r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
+    r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = noise_var; r.symmetric = 1;
+    r.out = out_dev; r.ld = ld;
+    HIP_TRY(launch_rbf((hipStream_t)stream, r));
+    return GPMI_OK;
+}
+
+int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const double* X_dev, int64_t N,
+                       int64_t d, int64_t row0, int64_t nrows, int64_t ncols, double sigma, double ell,
+                       double* out_dev, int64_t ld) {
+    if (!Xs_dev || !X_dev || !out_dev) return fail_arg("gpmi_dev_rbf_cross: null pointer");
+    if (nrows % TILE || ncols % TILE || ld < ncols || ld % 2)
+        return fail_arg("gpmi_dev_rbf_cross: sizes must be multiples of 128");
+    RbfArgs r;
+    r.A = Xs_dev; r.B = X_dev; r.nA = n; r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
+    r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
+    r.out = out_dev; r.ld = ld;
+    HIP_TRY(launch_rbf((hipStream_t)stream, r));
+    return GPMI_OK;
+}
+
+int gpmi_dev_potrf_block(void* stream, double* A_dev, int64_t ld, int64_t nb, int64_t col_offset,
+                         int64_t* info_dev) {
+    if (!A_dev || !info_dev) return fail_arg("gpmi_dev_potrf_block: null pointer");
+    if (nb <= 0 || nb % TILE || ld % 2) return fail_arg("gpmi_dev_potrf_block: nb must be a multiple of 128");
+    HIP_TRY(panel_factor((hipStream_t)stream, A_dev, ld, nb, nb, col_offset, info_dev));
+    return GPMI_OK;
+}
+
+int gpmi_dev_trsm_block(void* stream, const double* L_dev, int64_t ldl, double* X_dev, int64_t ldx,
+                        int64_t m, int64_t nb) {
+    if (!L_dev || !X_dev) return fail_arg("gpmi_dev_trsm_block: null pointer");
+    if (m < 0 || m % TILE || nb <= 0 || nb % IB || ldl % 2 || ldx % 2)
+        return fail_arg("gpmi_dev_trsm_block: m must be a multiple of 128, nb of 64");
+    if (m == 0) return GPMI_OK;
+    HIP_TRY(trsm_block((hipStream_t)stream, L_dev, ldl, X_dev, ldx, m, nb));
+    return GPMI_OK;
+}
+
+int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                     const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K, int lower,
+                     int64_t diag_off) {
+    if (!C_dev || !A_dev || !B_dev) return fail_arg("gpmi_dev_gemm_nt: null pointer");
+    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2)
+        return fail_arg("gpmi_dev_gemm_nt: M%128, N%64, K%16 must be 0");
+    GemmArgs g;
+    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = diag_off;
+    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
+    return GPMI_OK;
+}
+
+int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                            const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                            const int32_t* row_ncols_dev, int64_t row_block_rows) {
+    if (!C_dev || !A_dev || !B_dev || !row_ncols_dev) return fail_arg("gpmi_dev_gemm_nt_rowmap: null pointer");
+    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2 ||
+        row_block_rows <= 0 || row_block_rows % TILE)
+        return fail_arg("gpmi_dev_gemm_nt_rowmap: M%128, N%64, K%16, row_block_rows%128 must be 0");
+    GemmArgs g;
+    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = 0; g.diag_off = 0;
+    g.row_ncols = row_ncols_dev; g.row_block_tiles = (int)(row_block_rows / TILE);
+    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
+    return GPMI_OK;
+}
+
+int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
+                           int64_t nx, double* out2_dev) {
+    if (!out2_dev) return fail_arg("gpmi_dev_logdiag_sumsq: null output");
+    HIP_TRY(launch_logdiag_sumsq((hipStream_t)stream, A_dev, ld, n, x_dev, nx, out2_dev));
+    return GPMI_OK;
+}
+
+int gpmi_dev_gemv_t(void* stream, const double* A_dev, int64_t ld, int64_t nrows, int64_t ncols,
+                    const double* x_dev, double* y_dev, double* scratch_dev) {
+    if (!y_dev || !scratch_dev || (nrows > 0 && (!A_dev || !x_dev))) return fail_arg("gpmi_dev_gemv_t: null pointer");
+    if (nrows < 0 || ncols < 0) return fail_arg("gpmi_dev_gemv_t: negative size");
+    HIP_TRY(launch_gemv_t((hipStream_t)stream, A_dev, ld, nrows, ncols, x_dev, y_dev, scratch_dev));
+    return GPMI_OK;
+}
+
+int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_dev, int64_t n) {
+    if (!L_dev || !b_dev) return fail_arg("gpmi_dev_trsv_lt: null pointer");
+    if (n <= 0 || n % IB) return fail_arg("gpmi_dev_trsv_lt: n must be a positive multiple of 64");
+    HIP_TRY(launch_trsv_lt((hipStream_t)stream, L_dev, ld, b_dev, n));
+    return GPMI_OK;
+}
+
+int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
+                      const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
+    if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");
+    if (ncols % 2 || ld % 2) return fail_arg("gpmi_dev_row_dots: ncols and ld must be even");
+    HIP_TRY(launch_row_dots((hipStream_t)stream, V_dev, ld, nrows, ncols, m_dev, dot_out_dev, sq_out_dev));
+    return GPMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+// Single-GPU drivers behind the C-ABI: recursive panel factorisation, the recursive triangular
+// solve of a block, the blocked right-looking Cholesky with lookahead, the TRSM sweep for
+// v = L^-1 K_s (and for L^-T), and the fit (K build + Cholesky + LML) they add up to.
+// Data layout: see gpmi_api.hip.
+#include "gpmi_ctx.h"
+
+namespace gpmi {
+
+// ---------------------------------------------------------------------------
+// Panel factorisation: the nb-wide block column whose diagonal block starts at
+// A (global column col_offset), `mrows` rows tall (mrows >= nb, multiple of
+// 128).  Recursive halving down to 64 columns:
+//   factor the left half (all rows), update the right half with ONE MFMA GEMM of
+//   depth = width of the left half, factor the right half.
+// The leaves are the 64 x 64 potf2 and the substitution TRSM of every row below
+// it.  Same flops and the same number of launches as a flat right-looking sweep
+// in 64-column steps, but half of the update flops run at depth >= nb/4 instead of
+// 64, and the panel is streamed 2.3x less often.
+// ---------------------------------------------------------------------------
+hipError_t panel_rec(hipStream_t s, double* A, int64_t ld, int64_t mrows, int64_t off, int64_t w,
+                     int64_t col_offset, int64_t* info) {
+    hipError_t e;
+    if (w <= IB) {
+        double* Ajj = A + off * ld + off;
+        if ((e = launch_potf2_64(s, Ajj, ld, col_offset + off, info)) != hipSuccess) return e;
+        const int64_t below = mrows - off - IB;
+        if (below > 0) return launch_trsm_rlt64(s, Ajj, ld, A + (off + IB) * ld + off, ld, below);
+        return hipSuccess;
+    }
+    const int64_t h = (w / 2) / IB * IB;           // left width (multiple of 64, >= 64)
+    if ((e = panel_rec(s, A, ld, mrows, off, h, col_offset, info)) != hipSuccess) return e;
+    {
+        // right half -= (rows of the left half) * (its own rows of the left half)^T, lower part.
+        // Rows start at the 128-aligned row at or above off+h: the extra 64 rows (when off+h is
+        // not a multiple of 128) lie above the diagonal of the updated columns and are never read.
+        const int64_t c0 = off + h;
+        const int64_t r0 = c0 / TILE * TILE;
+        GemmArgs g;
+        g.C = A + r0 * ld + c0;
+        g.A = A + r0 * ld + off;
+        g.B = A + c0 * ld + off;
+        g.ldc = g.lda = g.ldb = ld;
+        g.M = mrows - r0; g.N = w - h; g.K = h;
+        g.mode = 0; g.lower = 1; g.diag_off = r0 - c0;
+        if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
+    }
+    return panel_rec(s, A, ld, mrows, off + h, w - h, col_offset, info);
+}
+
+hipError_t panel_factor(hipStream_t s, double* A, int64_t ld, int64_t nb, int64_t mrows,
+                        int64_t col_offset, int64_t* info) {
+    return panel_rec(s, A, ld, mrows, 0, nb, col_offset, info);
+}
+
+// X (m x nb) <- X * L^-T, L nb x nb lower; m multiple of 128, nb multiple of 64.
+// Same recursion: X1 <- X1 L11^-T;  X2 <- (X2 - X1 L21^T) L22^-T.
+hipError_t trsm_rec(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m,
+                    int64_t off, int64_t w) {
+    hipError_t e;
+    if (w <= IB) return launch_trsm_rlt64(s, L + off * ldl + off, ldl, X + off, ldx, m);
+    const int64_t h = (w / 2) / IB * IB;
+    if ((e = trsm_rec(s, L, ldl, X, ldx, m, off, h)) != hipSuccess) return e;
+    GemmArgs g;
+    g.C = X + off + h;
+    g.A = X + off;
+    g.B = L + (off + h) * ldl + off;
+    g.ldc = g.lda = ldx; g.ldb = ldl;
+    g.M = m; g.N = w - h; g.K = h;
+    g.mode = 0; g.lower = 0; g.diag_off = 0;
+    if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
+    return trsm_rec(s, L, ldl, X, ldx, m, off + h, w - h);
+}
+
+hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
+                      int64_t m, int64_t nb) {
+    return trsm_rec(s, L, ldl, X, ldx, m, 0, nb);
+}
+
+// Block widths of the sweep.  With a fixed width NB the first panel (NB columns x all rows) runs
+// before there is any trailing update to hide it behind, and the last few panels are longer than
+// the updates they overlap.  Option "ramp" lets the widths ramp up (NB/4, NB/4, NB/2, then NB)
+// and down again over the last columns.  Measured at N = 65536: the exposed panel time drops by
+// 7 ms but the narrower first updates cost 14 ms, so it is off by default.
+std::vector<int64_t> block_schedule(const gpmi_ctx* c, int64_t ncols) {
+    const int64_t NB = c->block(ncols);
+    std::vector<int64_t> w;
+    const bool ramp = c->nb == 0 && c->ramp && NB >= 1024 && ncols >= 8 * NB;
+    int64_t done = 0;
+    while (done < ncols) {
+        int64_t nb = NB;
+        if (ramp) {
+            const int64_t left = ncols - done;
+            if (w.size() < 2) nb = NB / 4;
+            else if (w.size() < 3) nb = NB / 2;
+            else if (left <= NB) nb = NB / 4;
+            else if (left <= 3 * NB) nb = NB / 2;
+        }
+        nb = std::min(nb, ncols - done);
+        w.push_back(nb);
+        done += nb;
+    }
+    return w;
+}
+
+// In-place blocked right-looking Cholesky of the leading ncols x ncols block of
+// A; rows ncols..nrows-1 are carried along (they end up multiplied by L^-T).
+//
+// With lookahead the trailing update of step k is split in two launches on the
+// main stream: (a) the next block column only, (b) the rest.  The panel stream
+// (high priority) factors panel k+1 as soon as (a) is done, i.e. concurrently
+// with (b), whose tiles it neither reads nor writes.  Dependencies:
+//   panel k  ->  (a)_k, (b)_k          (main waits on the panel event)
+//   (a)_k    ->  panel k+1             (panel stream waits on the column event)
+//   (b)_k    ->  (a)_{k+1}, (b)_{k+1}  (same stream)
+hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows,
+                            int64_t* info, bool account) {
+    hipError_t e;
+    hipStream_t sm = c->stream;
+    const std::vector<int64_t> widths = block_schedule(c, ncols);
+    const int64_t NB = c->block(ncols);
+    // below ~12k columns the two-stream choreography costs more than the panel it hides
+    const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
+    hipStream_t sp_ = la ? c->pstream : sm;
+    const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
+    const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
+    if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;   // panel 0 after the K build
+    auto trail = [&](int64_t r0, int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
+        // C = A[r0.., c0..c0+ncol_upd) -= A[r0.., k..k+nb) * A[c0.., k..k+nb)^T, lower part
+        GemmArgs g;
+        g.C = A + r0 * ld + c0;
+        g.A = A + r0 * ld + k;
+        g.B = A + c0 * ld + k;
+        g.ldc = g.lda = g.ldb = ld;
+        g.M = nrows - r0; g.N = ncol_upd; g.K = nb;
+        g.mode = 0; g.lower = 1; g.diag_off = r0 - c0;
+        g.role = 1;
+        // the roofline figures are those of the LDS-DMA kernel: the last, small updates that
+        // run on the first-generation kernel are timed into the scratch slot
+        const bool dma = gemm_nt_routes_dma(g);
+        size_t sp = c->span_begin(dma ? slot_t : GPMI_T_COUNT - 1, sm);
+        hipError_t er = launch_gemm_nt(sm, g);
+        c->span_end(sp, sm);
+        if (account && dma) {
+            c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
+            // algorithmic: the lower triangle of the real rows plus the one row that carries y
+            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_algorithmic_flops(g, ncols - r0 + 1);
+        }
+        return er;
+    };
+    int64_t k = 0;
+    for (size_t step = 0; step < widths.size(); ++step) {
+        const int64_t nb = widths[step];
+        size_t sp = c->span_begin(slot_p, sp_);
+        e = panel_factor(sp_, A + k * ld + k, ld, nb, nrows - k, k, info);
+        c->span_end(sp, sp_);
+        if (e != hipSuccess) return e;
+        if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
+        const int64_t r0 = k + nb;
+        k = r0;
+        if (r0 >= ncols) continue;
+        if (!la) {
+            if ((e = trail(r0, r0, r0 - nb, nb, ncols - r0)) != hipSuccess) return e;
+            continue;
+        }
+        const int64_t nbn = widths[step + 1];
+        if ((e = trail(r0, r0, r0 - nb, nb, nbn)) != hipSuccess) return e;           // (a) next block column
+        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
+        if (r0 + nbn < ncols &&
+            (e = trail(r0 + nbn, r0 + nbn, r0 - nb, nb, ncols - r0 - nbn)) != hipSuccess) return e;  // (b) rest
+    }
+    return hipSuccess;
+}
+
+void set_kernel_args(const gpmi_ctx* c, RbfArgs& r) {
+    r.coef = c->coef; r.sig2 = c->sig2;
+    r.kind = c->kind; r.kp0 = c->kp0; r.kp1 = c->kp1;
+    for (int i = 0; i < 11; ++i) r.kpv[i] = c->kpv[i];
+}
+
+int ensure_train_buffers(gpmi_ctx* c) {
+    c->Np = round_up(c->N, TILE);
+    c->ldA = c->Np + c->ld_pad;
+    c->Mp = c->Np + TILE;
+    HIP_TRY(c->A.ensure((size_t)c->Mp * c->ldA * sizeof(double)));
+    HIP_TRY(c->info.ensure(sizeof(int64_t)));
+    HIP_TRY(c->red.ensure(16 * sizeof(double)));
+    return GPMI_OK;
+}
+
+// K build + Cholesky (+ forward solve through the y row) + LML on the stream
+int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
+                   int64_t* bad_pivot) {
+    if (!c->have_train) return fail_arg("gpmi_factorize: no training set (call gpmi_set_train)");
+    if (c->kind == 0 && (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma)))
+        return fail_arg("gpmi_factorize: ell must be non-zero and hyper-parameters finite");
+    if (std::isnan(noise_var)) return fail_arg("gpmi_factorize: noise_var is NaN");
+    if (c->kind == 2 && c->d != 1) return fail_arg("gpmi_factorize: the periodic kernel is 1-D only (GP_regression.py:48)");
+    int rc = ensure_train_buffers(c);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    c->have_factor = false;
+    c->have_v = false;
+    c->timers_reset({GPMI_T_KBUILD, GPMI_T_CHOL, GPMI_T_CHOL_PANEL, GPMI_T_CHOL_TRAIL, GPMI_T_LML,
+                     GPMI_T_TRAIL_LAUNCHES, GPMI_T_TRAIL_FLOPS});
+    c->sig2 = sigma * sigma;
+    c->coef = -.5 * (1 / (ell * ell));      // GP_regression.py:19 evaluation order
+    c->sigma = sigma; c->ell = ell;
+    double* A = c->A.as<double>();
+    const int64_t big = std::numeric_limits<int64_t>::max();
+    HIP_TRY(hipMemcpyAsync(c->info.p, &big, sizeof big, hipMemcpyHostToDevice, s));
+
+    size_t sp = c->span_begin(GPMI_T_KBUILD);
+    RbfArgs r;
+    r.A = r.B = c->X.as<double>();
+    r.nA = r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->Np; r.ncols = c->Np;
+    set_kernel_args(c, r);
+    r.diag_add = noise_var; r.symmetric = 1; r.delta_square = 1;
+    r.max_sq = box_max_sq(c->boxX, c->boxX);
+    r.out = A; r.ld = c->ldA;
+    HIP_TRY(launch_rbf(s, r));
+    // the augmented rows: y then zeros
+    HIP_TRY(launch_fill_rows(s, A + c->Np * c->ldA, c->ldA, TILE, c->Np, 0.0));
+    HIP_TRY(launch_set_yrow(s, A + c->Np * c->ldA, c->y.as<double>(), c->N, c->Np));
+    c->span_end(sp);
+
+    sp = c->span_begin(GPMI_T_CHOL);
+    HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true));
+    c->span_end(sp);
+
+    sp = c->span_begin(GPMI_T_LML);
+    HIP_TRY(launch_lml_reduce(s, A, c->ldA, A + c->Np * c->ldA, c->N, c->red.as<double>()));
+    c->span_end(sp);
+
+    double red[2];
+    int64_t info;
+    HIP_TRY(hipMemcpyAsync(red, c->red.p, sizeof red, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof info, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    c->timers_collect();
+    if (info != big && info < c->N) {
+        if (bad_pivot) *bad_pivot = info + 1;
+        if (lml) *lml = std::numeric_limits<double>::quiet_NaN();
+        g_err = "Matrix is not positive definite";
+        return GPMI_ERR_NOT_PD;
+    }
+    if (bad_pivot) *bad_pivot = 0;
+    // tune_hyperparms_regression.py:312, with y^T alpha = m^T m
+    if (lml) *lml = -.5 * red[1] - red[0] - (double)c->N / 2.0 * std::log(2 * M_PI);
+    c->have_factor = true;
+    return GPMI_OK;
+}
+
+// v^T = K_s^T L^-T: right-looking sweep over the block columns of L, with the
+// same lookahead split as the Cholesky (the triangular solve of block column
+// k+1 overlaps the update of the columns beyond it).
+// tri: V starts as the identity (m == Np), so at step k only rows < k + nb are non-zero in
+// block column k -- the sweep then costs Np^3/3 and leaves the upper triangular L^-T.
+hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri) {
+    hipError_t e;
+    hipStream_t sm = c->stream;
+    const double* A = c->A.as<double>();
+    const int64_t ld = c->ldA, Np = c->Np;
+    const int64_t NB = c->block(Np);
+    const bool la = c->lookahead && c->pstream && Np > NB && Np >= 12288;
+    hipStream_t sp_ = la ? c->pstream : sm;
+    if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
+    auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
+        GemmArgs g;   // V[:, c0..c0+ncol_upd) -= V[:, k..k+nb) * L[c0.., k..k+nb)^T
+        g.C = V + c0; g.A = V + k; g.B = A + c0 * ld + k;
+        g.ldc = g.lda = ldv; g.ldb = ld;
+        g.M = tri ? std::min(m, k + nb) : m; g.N = ncol_upd; g.K = nb;
+        g.mode = 0; g.lower = 0; g.diag_off = 0;
+        return launch_gemm_nt(sm, g);
+    };
+    for (int64_t k = 0; k < Np; k += NB) {
+        const int64_t nb = std::min<int64_t>(NB, Np - k);
+        if ((e = trsm_block(sp_, A + k * ld + k, ld, V + k, ldv, tri ? std::min(m, k + nb) : m, nb)) != hipSuccess) return e;
+        if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
+        const int64_t r0 = k + nb;
+        if (r0 >= Np) continue;
+        if (!la) {
+            if ((e = update(r0, k, nb, Np - r0)) != hipSuccess) return e;
+            continue;
+        }
+        const int64_t nbn = std::min<int64_t>(NB, Np - r0);
+        if ((e = update(r0, k, nb, nbn)) != hipSuccess) return e;
+        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
+        if (r0 + nbn < Np && (e = update(r0 + nbn, k, nb, Np - r0 - nbn)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+}  // namespace gpmi

@@ -13,453 +13,13 @@
 //   V   n_p x ldV          row-major, row i = K(x*_i, X) then (L^-1 K_s)[:, i]
 //       (v transposed: both GEMM operands of the sweep stay K-contiguous).
 //   P   n_p x ldP          posterior covariance / its factor (gpmi_post_chol).
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <limits>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/gpmi.h"
-#include "gpmi_internal.h"
+#include "gpmi_ctx.h"
 
 using namespace gpmi;
 
-namespace {
-
+namespace gpmi {
 thread_local std::string g_err;
-
-int fail_runtime(hipError_t e, const char* what) {
-    char buf[512];
-    snprintf(buf, sizeof buf, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
-    g_err = buf;
-    return GPMI_ERR_RUNTIME;
 }
-int fail_arg(const char* what) {
-    g_err = what;
-    return GPMI_ERR_BAD_ARG;
-}
-
-#define HIP_TRY(expr)                                             \
-    do {                                                          \
-        hipError_t _e = (expr);                                   \
-        if (_e != hipSuccess) return fail_runtime(_e, #expr);     \
-    } while (0)
-
-inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) cap = bytes;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct TimedSpan { hipEvent_t a, b; int slot; };
-
-// Per-dimension bounding box of a point set (host side, at upload time).  Two boxes bound every
-// squared distance of a kernel-matrix launch, which lets the squared-exponential build drop its
-// per-wave exp domain test (RbfArgs::max_sq).  Non-finite inputs make the box invalid.
-struct Box {
-    std::vector<double> lo, hi;
-    bool valid = false;
-    void assign(const double* X, int64_t n, int64_t d) {
-        lo.assign((size_t)d, std::numeric_limits<double>::infinity());
-        hi.assign((size_t)d, -std::numeric_limits<double>::infinity());
-        bool finite = n > 0;
-        for (int64_t i = 0; i < n; ++i)
-            for (int64_t k = 0; k < d; ++k) {
-                const double v = X[i * d + k];
-                finite &= std::isfinite(v);
-                lo[(size_t)k] = std::min(lo[(size_t)k], v);
-                hi[(size_t)k] = std::max(hi[(size_t)k], v);
-            }
-        valid = finite;
-    }
-};
-double box_max_sq(const Box& a, const Box& b) {
-    if (!a.valid || !b.valid || a.lo.size() != b.lo.size()) return -1.0;
-    double s = 0.0;
-    for (size_t k = 0; k < a.lo.size(); ++k) {
-        const double w = std::max(a.hi[k] - b.lo[k], b.hi[k] - a.lo[k]);
-        s += w * w;
-    }
-    return std::isfinite(s) ? s : -1.0;
-}
-
-}  // namespace
-
-struct gpmi_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;    // main stream: K build, trailing updates, reductions
-    hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
-    // options
-    int64_t nb = 0;         // outer block width of the Cholesky (multiple of 128); 0 = by size
-    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 49152 ? 2048 : ncols >= 24576 ? 1024 : 512); }
-    int64_t ld_pad = 544;   // doubles added to every leading dimension
-    int timing = 1;
-    int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
-    int lanes = 0;          // gpmi_lml_batch: factorisations in flight (0 = by size)
-    std::vector<gpmi_ctx*> lane_ctx;   // the extra lanes (own streams and workspaces), created on demand
-    int ramp = 0;           // block widths ramp up at the start and down at the end of the sweep (measured: 0.4 % slower at N = 65536, off)
-    // training set / factor
-    int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
-    bool have_train = false, have_factor = false;
-    double sig2 = 1.0, coef = -0.5;
-    int kind = 0;            // covariance function: 0 rbf, 1 linear, 2 periodic, 3 CO2 composite (gpmi_set_kernel*)
-    double kp0 = 0., kp1 = 0.;
-    double kpv[11] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
-    DevBuf X, y, A, info, red;
-    // test set
-    int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
-    bool have_test = false, have_v = false;
-    std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
-    Box boxX, boxXs;         // bounding boxes of the training / test inputs
-    DevBuf Xs, V, P, vec, dense;
-    DevBuf U, Kn, gpart;     // f2: L^-T, -(K+sI)^-1, per-tile partial sums of the gradient trace
-    double sigma = 1.0, ell = 1.0;   // hyper-parameters of the resident factorisation
-    // timers
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_used = 0;
-    std::vector<TimedSpan> spans;
-    double stage_ms[GPMI_T_COUNT] = {0};
-
-    hipEvent_t new_event() {
-        if (ev_used == ev_pool.size()) {
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
-            ev_pool.push_back(e);
-        }
-        return ev_pool[ev_used++];
-    }
-    size_t span_begin(int slot, hipStream_t st = nullptr) {
-        if (!timing) return 0;
-        TimedSpan s{new_event(), new_event(), slot};
-        (void)hipEventRecord(s.a, st ? st : stream);
-        spans.push_back(s);
-        return spans.size() - 1;
-    }
-    void span_end(size_t idx, hipStream_t st = nullptr) {
-        if (!timing) return;
-        (void)hipEventRecord(spans[idx].b, st ? st : stream);
-    }
-    // make stream `waiter` wait for everything queued so far on `signaller`
-    hipError_t order(hipStream_t signaller, hipStream_t waiter) {
-        hipEvent_t e = new_event();
-        hipError_t r = hipEventRecord(e, signaller);
-        if (r != hipSuccess) return r;
-        return hipStreamWaitEvent(waiter, e, 0);
-    }
-    void timers_reset(std::initializer_list<int> slots) {
-        for (int s : slots) stage_ms[s] = 0.;
-    }
-    // call after the stream has been synchronised
-    void timers_collect() {
-        for (auto& s : spans) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) stage_ms[s.slot] += ms;
-        }
-        spans.clear();
-        ev_used = 0;
-    }
-};
-
-namespace {
-
-// ---------------------------------------------------------------------------
-// Panel factorisation: the nb-wide block column whose diagonal block starts at
-// A (global column col_offset), `mrows` rows tall (mrows >= nb, multiple of
-// 128).  Recursive halving down to 64 columns:
-//   factor the left half (all rows), update the right half with ONE MFMA GEMM of
-//   depth = width of the left half, factor the right half.
-// The leaves are the 64 x 64 potf2 and the substitution TRSM of every row below
-// it.  Same flops and the same number of launches as a flat right-looking sweep
-// in 64-column steps, but half of the update flops run at depth >= nb/4 instead of
-// 64, and the panel is streamed 2.3x less often.
-// ---------------------------------------------------------------------------
-hipError_t panel_rec(hipStream_t s, double* A, int64_t ld, int64_t mrows, int64_t off, int64_t w,
-                     int64_t col_offset, int64_t* info) {
-    hipError_t e;
-    if (w <= IB) {
-        double* Ajj = A + off * ld + off;
-        if ((e = launch_potf2_64(s, Ajj, ld, col_offset + off, info)) != hipSuccess) return e;
-        const int64_t below = mrows - off - IB;
-        if (below > 0) return launch_trsm_rlt64(s, Ajj, ld, A + (off + IB) * ld + off, ld, below);
-        return hipSuccess;
-    }
-    const int64_t h = (w / 2) / IB * IB;           // left width (multiple of 64, >= 64)
-    if ((e = panel_rec(s, A, ld, mrows, off, h, col_offset, info)) != hipSuccess) return e;
-    {
-        // right half -= (rows of the left half) * (its own rows of the left half)^T, lower part.
-        // Rows start at the 128-aligned row at or above off+h: the extra 64 rows (when off+h is
-        // not a multiple of 128) lie above the diagonal of the updated columns and are never read.
-        const int64_t c0 = off + h;
-        const int64_t r0 = c0 / TILE * TILE;
-        GemmArgs g;
-        g.C = A + r0 * ld + c0;
-        g.A = A + r0 * ld + off;
-        g.B = A + c0 * ld + off;
-        g.ldc = g.lda = g.ldb = ld;
-        g.M = mrows - r0; g.N = w - h; g.K = h;
-        g.mode = 0; g.lower = 1; g.diag_off = r0 - c0;
-        if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
-    }
-    return panel_rec(s, A, ld, mrows, off + h, w - h, col_offset, info);
-}
-
-hipError_t panel_factor(hipStream_t s, double* A, int64_t ld, int64_t nb, int64_t mrows,
-                        int64_t col_offset, int64_t* info) {
-    return panel_rec(s, A, ld, mrows, 0, nb, col_offset, info);
-}
-
-// X (m x nb) <- X * L^-T, L nb x nb lower; m multiple of 128, nb multiple of 64.
-// Same recursion: X1 <- X1 L11^-T;  X2 <- (X2 - X1 L21^T) L22^-T.
-hipError_t trsm_rec(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m,
-                    int64_t off, int64_t w) {
-    hipError_t e;
-    if (w <= IB) return launch_trsm_rlt64(s, L + off * ldl + off, ldl, X + off, ldx, m);
-    const int64_t h = (w / 2) / IB * IB;
-    if ((e = trsm_rec(s, L, ldl, X, ldx, m, off, h)) != hipSuccess) return e;
-    GemmArgs g;
-    g.C = X + off + h;
-    g.A = X + off;
-    g.B = L + (off + h) * ldl + off;
-    g.ldc = g.lda = ldx; g.ldb = ldl;
-    g.M = m; g.N = w - h; g.K = h;
-    g.mode = 0; g.lower = 0; g.diag_off = 0;
-    if ((e = launch_gemm_nt(s, g)) != hipSuccess) return e;
-    return trsm_rec(s, L, ldl, X, ldx, m, off + h, w - h);
-}
-
-hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
-                      int64_t m, int64_t nb) {
-    return trsm_rec(s, L, ldl, X, ldx, m, 0, nb);
-}
-
-// Block widths of the sweep.  With a fixed width NB the first panel (NB columns x all rows) runs
-// before there is any trailing update to hide it behind, and the last few panels are longer than
-// the updates they overlap.  Option "ramp" lets the widths ramp up (NB/4, NB/4, NB/2, then NB)
-// and down again over the last columns.  Measured at N = 65536: the exposed panel time drops by
-// 7 ms but the narrower first updates cost 14 ms, so it is off by default.
-std::vector<int64_t> block_schedule(const gpmi_ctx* c, int64_t ncols) {
-    const int64_t NB = c->block(ncols);
-    std::vector<int64_t> w;
-    const bool ramp = c->nb == 0 && c->ramp && NB >= 1024 && ncols >= 8 * NB;
-    int64_t done = 0;
-    while (done < ncols) {
-        int64_t nb = NB;
-        if (ramp) {
-            const int64_t left = ncols - done;
-            if (w.size() < 2) nb = NB / 4;
-            else if (w.size() < 3) nb = NB / 2;
-            else if (left <= NB) nb = NB / 4;
-            else if (left <= 3 * NB) nb = NB / 2;
-        }
-        nb = std::min(nb, ncols - done);
-        w.push_back(nb);
-        done += nb;
-    }
-    return w;
-}
-
-// In-place blocked right-looking Cholesky of the leading ncols x ncols block of
-// A; rows ncols..nrows-1 are carried along (they end up multiplied by L^-T).
-//
-// With lookahead the trailing update of step k is split in two launches on the
-// main stream: (a) the next block column only, (b) the rest.  The panel stream
-// (high priority) factors panel k+1 as soon as (a) is done, i.e. concurrently
-// with (b), whose tiles it neither reads nor writes.  Dependencies:
-//   panel k  ->  (a)_k, (b)_k          (main waits on the panel event)
-//   (a)_k    ->  panel k+1             (panel stream waits on the column event)
-//   (b)_k    ->  (a)_{k+1}, (b)_{k+1}  (same stream)
-hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows,
-                            int64_t* info, bool account) {
-    hipError_t e;
-    hipStream_t sm = c->stream;
-    const std::vector<int64_t> widths = block_schedule(c, ncols);
-    const int64_t NB = c->block(ncols);
-    // below ~12k columns the two-stream choreography costs more than the panel it hides
-    const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
-    hipStream_t sp_ = la ? c->pstream : sm;
-    const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
-    const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
-    if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;   // panel 0 after the K build
-    auto trail = [&](int64_t r0, int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
-        // C = A[r0.., c0..c0+ncol_upd) -= A[r0.., k..k+nb) * A[c0.., k..k+nb)^T, lower part
-        GemmArgs g;
-        g.C = A + r0 * ld + c0;
-        g.A = A + r0 * ld + k;
-        g.B = A + c0 * ld + k;
-        g.ldc = g.lda = g.ldb = ld;
-        g.M = nrows - r0; g.N = ncol_upd; g.K = nb;
-        g.mode = 0; g.lower = 1; g.diag_off = r0 - c0;
-        g.role = 1;
-        // the roofline figures are those of the LDS-DMA kernel: the last, small updates that
-        // run on the first-generation kernel are timed into the scratch slot
-        const bool dma = gemm_nt_routes_dma(g);
-        size_t sp = c->span_begin(dma ? slot_t : GPMI_T_COUNT - 1, sm);
-        hipError_t er = launch_gemm_nt(sm, g);
-        c->span_end(sp, sm);
-        if (account && dma) {
-            c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
-            // algorithmic: the lower triangle of the real rows plus the one row that carries y
-            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_algorithmic_flops(g, ncols - r0 + 1);
-        }
-        return er;
-    };
-    int64_t k = 0;
-    for (size_t step = 0; step < widths.size(); ++step) {
-        const int64_t nb = widths[step];
-        size_t sp = c->span_begin(slot_p, sp_);
-        e = panel_factor(sp_, A + k * ld + k, ld, nb, nrows - k, k, info);
-        c->span_end(sp, sp_);
-        if (e != hipSuccess) return e;
-        if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
-        const int64_t r0 = k + nb;
-        k = r0;
-        if (r0 >= ncols) continue;
-        if (!la) {
-            if ((e = trail(r0, r0, r0 - nb, nb, ncols - r0)) != hipSuccess) return e;
-            continue;
-        }
-        const int64_t nbn = widths[step + 1];
-        if ((e = trail(r0, r0, r0 - nb, nb, nbn)) != hipSuccess) return e;           // (a) next block column
-        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
-        if (r0 + nbn < ncols &&
-            (e = trail(r0 + nbn, r0 + nbn, r0 - nb, nb, ncols - r0 - nbn)) != hipSuccess) return e;  // (b) rest
-    }
-    return hipSuccess;
-}
-
-void set_kernel_args(const gpmi_ctx* c, RbfArgs& r) {
-    r.coef = c->coef; r.sig2 = c->sig2;
-    r.kind = c->kind; r.kp0 = c->kp0; r.kp1 = c->kp1;
-    for (int i = 0; i < 11; ++i) r.kpv[i] = c->kpv[i];
-}
-
-int ensure_train_buffers(gpmi_ctx* c) {
-    c->Np = round_up(c->N, TILE);
-    c->ldA = c->Np + c->ld_pad;
-    c->Mp = c->Np + TILE;
-    HIP_TRY(c->A.ensure((size_t)c->Mp * c->ldA * sizeof(double)));
-    HIP_TRY(c->info.ensure(sizeof(int64_t)));
-    HIP_TRY(c->red.ensure(16 * sizeof(double)));
-    return GPMI_OK;
-}
-
-// K build + Cholesky (+ forward solve through the y row) + LML on the stream
-int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
-                   int64_t* bad_pivot) {
-    if (!c->have_train) return fail_arg("gpmi_factorize: no training set (call gpmi_set_train)");
-    if (c->kind == 0 && (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma)))
-        return fail_arg("gpmi_factorize: ell must be non-zero and hyper-parameters finite");
-    if (std::isnan(noise_var)) return fail_arg("gpmi_factorize: noise_var is NaN");
-    if (c->kind == 2 && c->d != 1) return fail_arg("gpmi_factorize: the periodic kernel is 1-D only (GP_regression.py:48)");
-    int rc = ensure_train_buffers(c);
-    if (rc) return rc;
-    hipStream_t s = c->stream;
-    c->have_factor = false;
-    c->have_v = false;
-    c->timers_reset({GPMI_T_KBUILD, GPMI_T_CHOL, GPMI_T_CHOL_PANEL, GPMI_T_CHOL_TRAIL, GPMI_T_LML,
-                     GPMI_T_TRAIL_LAUNCHES, GPMI_T_TRAIL_FLOPS});
-    c->sig2 = sigma * sigma;
-    c->coef = -.5 * (1 / (ell * ell));      // GP_regression.py:19 evaluation order
-    c->sigma = sigma; c->ell = ell;
-    double* A = c->A.as<double>();
-    const int64_t big = std::numeric_limits<int64_t>::max();
-    HIP_TRY(hipMemcpyAsync(c->info.p, &big, sizeof big, hipMemcpyHostToDevice, s));
-
-    size_t sp = c->span_begin(GPMI_T_KBUILD);
-    RbfArgs r;
-    r.A = r.B = c->X.as<double>();
-    r.nA = r.nB = c->N; r.d = c->d; r.row0 = 0; r.nrows = c->Np; r.ncols = c->Np;
-    set_kernel_args(c, r);
-    r.diag_add = noise_var; r.symmetric = 1; r.delta_square = 1;
-    r.max_sq = box_max_sq(c->boxX, c->boxX);
-    r.out = A; r.ld = c->ldA;
-    HIP_TRY(launch_rbf(s, r));
-    // the augmented rows: y then zeros
-    HIP_TRY(launch_fill_rows(s, A + c->Np * c->ldA, c->ldA, TILE, c->Np, 0.0));
-    HIP_TRY(launch_set_yrow(s, A + c->Np * c->ldA, c->y.as<double>(), c->N, c->Np));
-    c->span_end(sp);
-
-    sp = c->span_begin(GPMI_T_CHOL);
-    HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true));
-    c->span_end(sp);
-
-    sp = c->span_begin(GPMI_T_LML);
-    HIP_TRY(launch_lml_reduce(s, A, c->ldA, A + c->Np * c->ldA, c->N, c->red.as<double>()));
-    c->span_end(sp);
-
-    double red[2];
-    int64_t info;
-    HIP_TRY(hipMemcpyAsync(red, c->red.p, sizeof red, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof info, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    c->timers_collect();
-    if (info != big && info < c->N) {
-        if (bad_pivot) *bad_pivot = info + 1;
-        if (lml) *lml = std::numeric_limits<double>::quiet_NaN();
-        g_err = "Matrix is not positive definite";
-        return GPMI_ERR_NOT_PD;
-    }
-    if (bad_pivot) *bad_pivot = 0;
-    // tune_hyperparms_regression.py:312, with y^T alpha = m^T m
-    if (lml) *lml = -.5 * red[1] - red[0] - (double)c->N / 2.0 * std::log(2 * M_PI);
-    c->have_factor = true;
-    return GPMI_OK;
-}
-
-// v^T = K_s^T L^-T: right-looking sweep over the block columns of L, with the
-// same lookahead split as the Cholesky (the triangular solve of block column
-// k+1 overlaps the update of the columns beyond it).
-// tri: V starts as the identity (m == Np), so at step k only rows < k + nb are non-zero in
-// block column k -- the sweep then costs Np^3/3 and leaves the upper triangular L^-T.
-hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri = false) {
-    hipError_t e;
-    hipStream_t sm = c->stream;
-    const double* A = c->A.as<double>();
-    const int64_t ld = c->ldA, Np = c->Np;
-    const int64_t NB = c->block(Np);
-    const bool la = c->lookahead && c->pstream && Np > NB && Np >= 12288;
-    hipStream_t sp_ = la ? c->pstream : sm;
-    if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
-    auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
-        GemmArgs g;   // V[:, c0..c0+ncol_upd) -= V[:, k..k+nb) * L[c0.., k..k+nb)^T
-        g.C = V + c0; g.A = V + k; g.B = A + c0 * ld + k;
-        g.ldc = g.lda = ldv; g.ldb = ld;
-        g.M = tri ? std::min(m, k + nb) : m; g.N = ncol_upd; g.K = nb;
-        g.mode = 0; g.lower = 0; g.diag_off = 0;
-        return launch_gemm_nt(sm, g);
-    };
-    for (int64_t k = 0; k < Np; k += NB) {
-        const int64_t nb = std::min<int64_t>(NB, Np - k);
-        if ((e = trsm_block(sp_, A + k * ld + k, ld, V + k, ldv, tri ? std::min(m, k + nb) : m, nb)) != hipSuccess) return e;
-        if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
-        const int64_t r0 = k + nb;
-        if (r0 >= Np) continue;
-        if (!la) {
-            if ((e = update(r0, k, nb, Np - r0)) != hipSuccess) return e;
-            continue;
-        }
-        const int64_t nbn = std::min<int64_t>(NB, Np - r0);
-        if ((e = update(r0, k, nb, nbn)) != hipSuccess) return e;
-        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
-        if (r0 + nbn < Np && (e = update(r0 + nbn, k, nb, Np - r0 - nbn)) != hipSuccess) return e;
-    }
-    return hipSuccess;
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -1091,246 +651,4 @@ int gpmi_get_timers(gpmi_ctx* c, double* stage_ms, int count) {
 }
 
 // out[0] = TFLOP/s, out[1] = shader clock (GHz) held during the loop,
-// out[2] = shader cycles per MFMA per SIMD
-int gpmi_probe_mfma_f64_ex(gpmi_ctx* c, int blocks_per_cu, int nacc, int iters, double* out) {
-    if (!c || !out) return fail_arg("gpmi_probe_mfma_f64_ex: null argument");
-    if (blocks_per_cu < 1 || blocks_per_cu > 8 || iters < 1) return fail_arg("gpmi_probe_mfma_f64_ex: bad argument");
-    if (nacc != 4 && nacc != 8 && nacc != 16) return fail_arg("gpmi_probe_mfma_f64_ex: nacc must be 4, 8 or 16");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(c->red.ensure(16 * 8));
-    hipStream_t s = c->stream;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    const int blocks = prop.multiProcessorCount * blocks_per_cu;
-    double* sink = c->red.as<double>();
-    unsigned long long* clk = reinterpret_cast<unsigned long long*>(sink + 8);
-    HIP_TRY(launch_probe_mfma(s, sink, 64, blocks, nacc, clk));   // warm-up
-    hipEvent_t a, b;
-    HIP_TRY(hipEventCreate(&a));
-    HIP_TRY(hipEventCreate(&b));
-    HIP_TRY(hipEventRecord(a, s));
-    HIP_TRY(launch_probe_mfma(s, sink, iters, blocks, nacc, clk));
-    HIP_TRY(hipEventRecord(b, s));
-    HIP_TRY(hipEventSynchronize(b));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    unsigned long long h[2];
-    HIP_TRY(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost));
-    const double n_mfma_wave = (double)iters * nacc;
-    out[0] = (double)blocks * 4 * n_mfma_wave * 2048.0 / (ms * 1e-3) / 1e12;
-    out[1] = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.;      // s_memrealtime ticks at 100 MHz
-    out[2] = (double)h[0] / (n_mfma_wave * blocks_per_cu);           // waves per SIMD = blocks per CU
-    return GPMI_OK;
-}
-
-int gpmi_probe_mfma_f64(gpmi_ctx* c, double* tflops) {
-    if (!tflops) return fail_arg("gpmi_probe_mfma_f64: null argument");
-    double out[3];
-    int rc = gpmi_probe_mfma_f64_ex(c, 2, 16, 2048, out);
-    if (rc == GPMI_OK) *tflops = out[0];
-    return rc;
-}
-
-// Timing of one GEMM launch shape on scratch buffers (results discarded).
-// variant: ablation bits (1: no global loads in the K loop, 2: no LDS writes / barriers,
-// 4: epilogue without the C read, 8: no epilogue).  out[0] = TFLOP/s over computed tiles,
-// out[1] = ms per launch.
-int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps,
-                    double* out) {
-    if (!c || !out) return fail_arg("gpmi_probe_gemm: null argument");
-    if (M <= 0 || N <= 0 || K <= 0 || M % TILE || N % IB || K % 16 || reps < 1)
-        return fail_arg("gpmi_probe_gemm: M%128, N%64, K%16 must be 0");
-    HIP_TRY(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
-    const int64_t ldc = N + c->ld_pad, ldk = K + c->ld_pad;
-    DevBuf C, A, B;
-    int rc = GPMI_OK;
-    hipError_t e;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    do {
-        if ((e = C.ensure((size_t)M * ldc * 8)) != hipSuccess || (e = A.ensure((size_t)M * ldk * 8)) != hipSuccess ||
-            (e = B.ensure((size_t)N * ldk * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
-        (void)hipMemsetAsync(C.p, 0, (size_t)M * ldc * 8, s);
-        (void)launch_fill_rows(s, A.as<double>(), ldk, M, K, 0.001);
-        (void)launch_fill_rows(s, B.as<double>(), ldk, N, K, -0.002);
-        GemmArgs g;
-        g.C = C.as<double>(); g.A = A.as<double>(); g.B = B.as<double>();
-        g.ldc = ldc; g.lda = g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = 0;
-        DevBuf stamps;
-        if (variant & 16) {
-            if ((e = stamps.ensure(4096 * 16 * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
-            (void)hipMemsetAsync(stamps.p, 0, 4096 * 16 * 8, s);
-            g_gemm_stamps = stamps.as<unsigned long long>();
-        }
-        g_gemm_dbg = variant;
-        e = launch_gemm_nt(s, g);
-        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
-        (void)hipEventRecord(ea, s);
-        for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_gemm_nt(s, g);
-        (void)hipEventRecord(eb, s);
-        hipError_t e2 = hipEventSynchronize(eb);
-        g_gemm_dbg = 0;
-        if (e != hipSuccess) { rc = fail_runtime(e, "gemm launch"); break; }
-        if (e2 != hipSuccess) { rc = fail_runtime(e2, "gemm sync"); break; }
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, ea, eb);
-        out[1] = ms / reps;
-        out[0] = gemm_nt_flops(g) / (out[1] * 1e-3) / 1e12;
-        if (variant & 16) {
-            std::vector<unsigned long long> h(4096 * 16);
-            (void)hipMemcpy(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost);
-            double sum[4] = {0, 0, 0, 0};
-            int cnt = 0;
-            for (size_t i = 0; i < h.size(); i += 4)
-                if (h[i + 1]) { for (int q = 0; q < 4; ++q) sum[q] += (double)h[i + q]; ++cnt; }
-            if (cnt) fprintf(stderr, "[gemm stamps] waves %d: prologue %.0f  loop %.0f  epilogue-loads %.0f  epilogue-stores %.0f cycles\n",
-                             cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt);
-            g_gemm_stamps = nullptr;
-            stamps.release();
-        }
-    } while (0);
-    g_gemm_dbg = 0;
-    if (ea) (void)hipEventDestroy(ea);
-    if (eb) (void)hipEventDestroy(eb);
-    (void)hipStreamSynchronize(s);
-    C.release(); A.release(); B.release();
-    return rc;
-}
-
-int gpmi_probe_hbm_ex(gpmi_ctx* c, int64_t bytes, int mode, int blocks, double* gbps) {
-    if (!c || !gbps || bytes < 4096 || blocks < 1 || mode < 0 || mode > 6) return fail_arg("gpmi_probe_hbm_ex: bad argument");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(c->red.ensure(16 * 8));
-    hipStream_t s = c->stream;
-    DevBuf buf;
-    HIP_TRY(buf.ensure((size_t)bytes));
-    hipError_t e = launch_probe_write(s, buf.as<double>(), bytes / 8, mode == 4 ? 0 : mode, blocks, c->red.as<double>());
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, s);
-    const int reps = 3;
-    for (int r = 0; r < reps && e == hipSuccess; ++r)
-        e = launch_probe_write(s, buf.as<double>(), bytes / 8, mode, blocks, c->red.as<double>());
-    (void)hipEventRecord(b, s);
-    hipError_t e2 = hipEventSynchronize(b);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, a, b);
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    buf.release();
-    if (e != hipSuccess) return fail_runtime(e, "probe kernel");
-    if (e2 != hipSuccess) return fail_runtime(e2, "probe sync");
-    *gbps = (double)bytes * reps / (ms * 1e-3) / 1e9;
-    return GPMI_OK;
-}
-
-int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
-    return gpmi_probe_hbm_ex(c, bytes, 0, 2048, gbps);
-}
-
-// ---- device-pointer block primitives (multi-GPU driver) -------------------------
-int gpmi_dev_rbf_rows(void* stream, const double* X_dev, int64_t N, int64_t d, int64_t row0,
-                      int64_t nrows, int64_t ncols, double sigma, double ell, double noise_var,
-                      double* out_dev, int64_t ld) {
-    if (!X_dev || !out_dev) return fail_arg("gpmi_dev_rbf_rows: null pointer");
-    if (nrows % TILE || ncols % TILE || row0 % TILE || ld < ncols || ld % 2)
-        return fail_arg("gpmi_dev_rbf_rows: sizes must be multiples of 128");
-    RbfArgs r;
-    r.A = r.B = X_dev; r.nA = r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
-    r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = noise_var; r.symmetric = 1;
-    r.out = out_dev; r.ld = ld;
-    HIP_TRY(launch_rbf((hipStream_t)stream, r));
-    return GPMI_OK;
-}
-
-int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const double* X_dev, int64_t N,
-                       int64_t d, int64_t row0, int64_t nrows, int64_t ncols, double sigma, double ell,
-                       double* out_dev, int64_t ld) {
-    if (!Xs_dev || !X_dev || !out_dev) return fail_arg("gpmi_dev_rbf_cross: null pointer");
-    if (nrows % TILE || ncols % TILE || ld < ncols || ld % 2)
-        return fail_arg("gpmi_dev_rbf_cross: sizes must be multiples of 128");
-    RbfArgs r;
-    r.A = Xs_dev; r.B = X_dev; r.nA = n; r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
-    r.coef = -.5 * (1 / (ell * ell)); r.sig2 = sigma * sigma; r.diag_add = 0.; r.symmetric = 0;
-    r.out = out_dev; r.ld = ld;
-    HIP_TRY(launch_rbf((hipStream_t)stream, r));
-    return GPMI_OK;
-}
-
-int gpmi_dev_potrf_block(void* stream, double* A_dev, int64_t ld, int64_t nb, int64_t col_offset,
-                         int64_t* info_dev) {
-    if (!A_dev || !info_dev) return fail_arg("gpmi_dev_potrf_block: null pointer");
-    if (nb <= 0 || nb % TILE || ld % 2) return fail_arg("gpmi_dev_potrf_block: nb must be a multiple of 128");
-    HIP_TRY(panel_factor((hipStream_t)stream, A_dev, ld, nb, nb, col_offset, info_dev));
-    return GPMI_OK;
-}
-
-int gpmi_dev_trsm_block(void* stream, const double* L_dev, int64_t ldl, double* X_dev, int64_t ldx,
-                        int64_t m, int64_t nb) {
-    if (!L_dev || !X_dev) return fail_arg("gpmi_dev_trsm_block: null pointer");
-    if (m < 0 || m % TILE || nb <= 0 || nb % IB || ldl % 2 || ldx % 2)
-        return fail_arg("gpmi_dev_trsm_block: m must be a multiple of 128, nb of 64");
-    if (m == 0) return GPMI_OK;
-    HIP_TRY(trsm_block((hipStream_t)stream, L_dev, ldl, X_dev, ldx, m, nb));
-    return GPMI_OK;
-}
-
-int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
-                     const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K, int lower,
-                     int64_t diag_off) {
-    if (!C_dev || !A_dev || !B_dev) return fail_arg("gpmi_dev_gemm_nt: null pointer");
-    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2)
-        return fail_arg("gpmi_dev_gemm_nt: M%128, N%64, K%16 must be 0");
-    GemmArgs g;
-    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
-    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = diag_off;
-    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
-    return GPMI_OK;
-}
-
-int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
-                            const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                            const int32_t* row_ncols_dev, int64_t row_block_rows) {
-    if (!C_dev || !A_dev || !B_dev || !row_ncols_dev) return fail_arg("gpmi_dev_gemm_nt_rowmap: null pointer");
-    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2 ||
-        row_block_rows <= 0 || row_block_rows % TILE)
-        return fail_arg("gpmi_dev_gemm_nt_rowmap: M%128, N%64, K%16, row_block_rows%128 must be 0");
-    GemmArgs g;
-    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
-    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = 0; g.diag_off = 0;
-    g.row_ncols = row_ncols_dev; g.row_block_tiles = (int)(row_block_rows / TILE);
-    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
-    return GPMI_OK;
-}
-
-int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
-                           int64_t nx, double* out2_dev) {
-    if (!out2_dev) return fail_arg("gpmi_dev_logdiag_sumsq: null output");
-    HIP_TRY(launch_logdiag_sumsq((hipStream_t)stream, A_dev, ld, n, x_dev, nx, out2_dev));
-    return GPMI_OK;
-}
-
-int gpmi_dev_gemv_t(void* stream, const double* A_dev, int64_t ld, int64_t nrows, int64_t ncols,
-                    const double* x_dev, double* y_dev, double* scratch_dev) {
-    if (!y_dev || !scratch_dev || (nrows > 0 && (!A_dev || !x_dev))) return fail_arg("gpmi_dev_gemv_t: null pointer");
-    if (nrows < 0 || ncols < 0) return fail_arg("gpmi_dev_gemv_t: negative size");
-    HIP_TRY(launch_gemv_t((hipStream_t)stream, A_dev, ld, nrows, ncols, x_dev, y_dev, scratch_dev));
-    return GPMI_OK;
-}
-
-int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_dev, int64_t n) {
-    if (!L_dev || !b_dev) return fail_arg("gpmi_dev_trsv_lt: null pointer");
-    if (n <= 0 || n % IB) return fail_arg("gpmi_dev_trsv_lt: n must be a positive multiple of 64");
-    HIP_TRY(launch_trsv_lt((hipStream_t)stream, L_dev, ld, b_dev, n));
-    return GPMI_OK;
-}
-
-int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
-                      const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
-    if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");
-    if (ncols % 2 || ld % 2) return fail_arg("gpmi_dev_row_dots: ncols and ld must be even");
-    HIP_TRY(launch_row_dots((hipStream_t)stream, V_dev, ld, nrows, ncols, m_dev, dot_out_dev, sq_out_dev));
-    return GPMI_OK;
-}
-
 }  // extern "C"

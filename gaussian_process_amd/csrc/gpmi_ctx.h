@@ -1,0 +1,181 @@
+// Internal to libgpmi355x.so: the context object behind the opaque gpmi_ctx handle, the error
+// helpers every translation unit of the C-ABI shares, and the single-GPU drivers (driver.hip).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gpmi.h"
+#include "gpmi_internal.h"
+
+namespace gpmi {
+
+extern thread_local std::string g_err;      // text behind gpmi_last_error() (gpmi_api.hip)
+
+inline int fail_runtime(hipError_t e, const char* what) {
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
+    g_err = buf;
+    return GPMI_ERR_RUNTIME;
+}
+inline int fail_arg(const char* what) {
+    g_err = what;
+    return GPMI_ERR_BAD_ARG;
+}
+
+#define HIP_TRY(expr)                                             \
+    do {                                                          \
+        hipError_t _e = (expr);                                   \
+        if (_e != hipSuccess) return fail_runtime(_e, #expr);     \
+    } while (0)
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct TimedSpan { hipEvent_t a, b; int slot; };
+
+// Per-dimension bounding box of a point set (host side, at upload time).  Two boxes bound every
+// squared distance of a kernel-matrix launch, which lets the squared-exponential build drop its
+// per-wave exp domain test (RbfArgs::max_sq).  Non-finite inputs make the box invalid.
+struct Box {
+    std::vector<double> lo, hi;
+    bool valid = false;
+    void assign(const double* X, int64_t n, int64_t d) {
+        lo.assign((size_t)d, std::numeric_limits<double>::infinity());
+        hi.assign((size_t)d, -std::numeric_limits<double>::infinity());
+        bool finite = n > 0;
+        for (int64_t i = 0; i < n; ++i)
+            for (int64_t k = 0; k < d; ++k) {
+                const double v = X[i * d + k];
+                finite &= std::isfinite(v);
+                lo[(size_t)k] = std::min(lo[(size_t)k], v);
+                hi[(size_t)k] = std::max(hi[(size_t)k], v);
+            }
+        valid = finite;
+    }
+};
+inline double box_max_sq(const Box& a, const Box& b) {
+    if (!a.valid || !b.valid || a.lo.size() != b.lo.size()) return -1.0;
+    double s = 0.0;
+    for (size_t k = 0; k < a.lo.size(); ++k) {
+        const double w = std::max(a.hi[k] - b.lo[k], b.hi[k] - a.lo[k]);
+        s += w * w;
+    }
+    return std::isfinite(s) ? s : -1.0;
+}
+
+}  // namespace gpmi
+
+// the handle type of include/gpmi.h lives at global scope
+using gpmi::Box;
+using gpmi::DevBuf;
+using gpmi::TimedSpan;
+
+struct gpmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;    // main stream: K build, trailing updates, reductions
+    hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
+    // options
+    int64_t nb = 0;         // outer block width of the Cholesky (multiple of 128); 0 = by size
+    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 49152 ? 2048 : ncols >= 24576 ? 1024 : 512); }
+    int64_t ld_pad = 544;   // doubles added to every leading dimension
+    int timing = 1;
+    int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
+    int lanes = 0;          // gpmi_lml_batch: factorisations in flight (0 = by size)
+    std::vector<gpmi_ctx*> lane_ctx;   // the extra lanes (own streams and workspaces), created on demand
+    int ramp = 0;           // block widths ramp up at the start and down at the end of the sweep (measured: 0.4 % slower at N = 65536, off)
+    // training set / factor
+    int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
+    bool have_train = false, have_factor = false;
+    double sig2 = 1.0, coef = -0.5;
+    int kind = 0;            // covariance function: 0 rbf, 1 linear, 2 periodic, 3 CO2 composite (gpmi_set_kernel*)
+    double kp0 = 0., kp1 = 0.;
+    double kpv[11] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
+    DevBuf X, y, A, info, red;
+    // test set
+    int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
+    bool have_test = false, have_v = false;
+    std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
+    Box boxX, boxXs;         // bounding boxes of the training / test inputs
+    DevBuf Xs, V, P, vec, dense;
+    DevBuf U, Kn, gpart;     // f2: L^-T, -(K+sI)^-1, per-tile partial sums of the gradient trace
+    double sigma = 1.0, ell = 1.0;   // hyper-parameters of the resident factorisation
+    // timers
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<TimedSpan> spans;
+    double stage_ms[GPMI_T_COUNT] = {0};
+
+    hipEvent_t new_event() {
+        if (ev_used == ev_pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            ev_pool.push_back(e);
+        }
+        return ev_pool[ev_used++];
+    }
+    size_t span_begin(int slot, hipStream_t st = nullptr) {
+        if (!timing) return 0;
+        TimedSpan s{new_event(), new_event(), slot};
+        (void)hipEventRecord(s.a, st ? st : stream);
+        spans.push_back(s);
+        return spans.size() - 1;
+    }
+    void span_end(size_t idx, hipStream_t st = nullptr) {
+        if (!timing) return;
+        (void)hipEventRecord(spans[idx].b, st ? st : stream);
+    }
+    // make stream `waiter` wait for everything queued so far on `signaller`
+    hipError_t order(hipStream_t signaller, hipStream_t waiter) {
+        hipEvent_t e = new_event();
+        hipError_t r = hipEventRecord(e, signaller);
+        if (r != hipSuccess) return r;
+        return hipStreamWaitEvent(waiter, e, 0);
+    }
+    void timers_reset(std::initializer_list<int> slots) {
+        for (int s : slots) stage_ms[s] = 0.;
+    }
+    // call after the stream has been synchronised
+    void timers_collect() {
+        for (auto& s : spans) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) stage_ms[s.slot] += ms;
+        }
+        spans.clear();
+        ev_used = 0;
+    }
+};
+
+
+namespace gpmi {
+
+// driver.hip
+hipError_t panel_factor(hipStream_t s, double* A, int64_t ld, int64_t nb, int64_t mrows, int64_t col_offset,
+                        int64_t* info);
+hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m, int64_t nb);
+hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows, int64_t* info,
+                            bool account);
+hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri = false);
+void set_kernel_args(const gpmi_ctx* c, RbfArgs& r);
+int ensure_train_buffers(gpmi_ctx* c);
+int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot);
+
+}  // namespace gpmi

@@ -1,0 +1,146 @@
+// Measurement probes of the C-ABI (fp64 MFMA issue rate, GEMM kernel ablations, HBM store patterns):
+// what scripts/probe*.py and the numbers in DESIGN.md section 4 come from.  Not on the product path.
+#include "gpmi_ctx.h"
+
+using namespace gpmi;
+
+extern "C" {
+
+// out[2] = shader cycles per MFMA per SIMD
+int gpmi_probe_mfma_f64_ex(gpmi_ctx* c, int blocks_per_cu, int nacc, int iters, double* out) {
+    if (!c || !out) return fail_arg("gpmi_probe_mfma_f64_ex: null argument");
+    if (blocks_per_cu < 1 || blocks_per_cu > 8 || iters < 1) return fail_arg("gpmi_probe_mfma_f64_ex: bad argument");
+    if (nacc != 4 && nacc != 8 && nacc != 16) return fail_arg("gpmi_probe_mfma_f64_ex: nacc must be 4, 8 or 16");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->red.ensure(16 * 8));
+    hipStream_t s = c->stream;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    const int blocks = prop.multiProcessorCount * blocks_per_cu;
+    double* sink = c->red.as<double>();
+    unsigned long long* clk = reinterpret_cast<unsigned long long*>(sink + 8);
+    HIP_TRY(launch_probe_mfma(s, sink, 64, blocks, nacc, clk));   // warm-up
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, s));
+    HIP_TRY(launch_probe_mfma(s, sink, iters, blocks, nacc, clk));
+    HIP_TRY(hipEventRecord(b, s));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, clk, sizeof h, hipMemcpyDeviceToHost));
+    const double n_mfma_wave = (double)iters * nacc;
+    out[0] = (double)blocks * 4 * n_mfma_wave * 2048.0 / (ms * 1e-3) / 1e12;
+    out[1] = h[1] ? (double)h[0] / ((double)h[1] * 10.0) : 0.;      // s_memrealtime ticks at 100 MHz
+    out[2] = (double)h[0] / (n_mfma_wave * blocks_per_cu);           // waves per SIMD = blocks per CU
+    return GPMI_OK;
+}
+
+int gpmi_probe_mfma_f64(gpmi_ctx* c, double* tflops) {
+    if (!tflops) return fail_arg("gpmi_probe_mfma_f64: null argument");
+    double out[3];
+    int rc = gpmi_probe_mfma_f64_ex(c, 2, 16, 2048, out);
+    if (rc == GPMI_OK) *tflops = out[0];
+    return rc;
+}
+
+// Timing of one GEMM launch shape on scratch buffers (results discarded).
+// variant: ablation bits (1: no global loads in the K loop, 2: no LDS writes / barriers,
+// 4: epilogue without the C read, 8: no epilogue).  out[0] = TFLOP/s over computed tiles,
+// out[1] = ms per launch.
+int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps,
+                    double* out) {
+    if (!c || !out) return fail_arg("gpmi_probe_gemm: null argument");
+    if (M <= 0 || N <= 0 || K <= 0 || M % TILE || N % IB || K % 16 || reps < 1)
+        return fail_arg("gpmi_probe_gemm: M%128, N%64, K%16 must be 0");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t ldc = N + c->ld_pad, ldk = K + c->ld_pad;
+    DevBuf C, A, B;
+    int rc = GPMI_OK;
+    hipError_t e;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    do {
+        if ((e = C.ensure((size_t)M * ldc * 8)) != hipSuccess || (e = A.ensure((size_t)M * ldk * 8)) != hipSuccess ||
+            (e = B.ensure((size_t)N * ldk * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
+        (void)hipMemsetAsync(C.p, 0, (size_t)M * ldc * 8, s);
+        (void)launch_fill_rows(s, A.as<double>(), ldk, M, K, 0.001);
+        (void)launch_fill_rows(s, B.as<double>(), ldk, N, K, -0.002);
+        GemmArgs g;
+        g.C = C.as<double>(); g.A = A.as<double>(); g.B = B.as<double>();
+        g.ldc = ldc; g.lda = g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = 0;
+        DevBuf stamps;
+        if (variant & 16) {
+            if ((e = stamps.ensure(4096 * 16 * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
+            (void)hipMemsetAsync(stamps.p, 0, 4096 * 16 * 8, s);
+            g_gemm_stamps = stamps.as<unsigned long long>();
+        }
+        g_gemm_dbg = variant;
+        e = launch_gemm_nt(s, g);
+        (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
+        (void)hipEventRecord(ea, s);
+        for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_gemm_nt(s, g);
+        (void)hipEventRecord(eb, s);
+        hipError_t e2 = hipEventSynchronize(eb);
+        g_gemm_dbg = 0;
+        if (e != hipSuccess) { rc = fail_runtime(e, "gemm launch"); break; }
+        if (e2 != hipSuccess) { rc = fail_runtime(e2, "gemm sync"); break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ea, eb);
+        out[1] = ms / reps;
+        out[0] = gemm_nt_flops(g) / (out[1] * 1e-3) / 1e12;
+        if (variant & 16) {
+            std::vector<unsigned long long> h(4096 * 16);
+            (void)hipMemcpy(h.data(), stamps.p, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[4] = {0, 0, 0, 0};
+            int cnt = 0;
+            for (size_t i = 0; i < h.size(); i += 4)
+                if (h[i + 1]) { for (int q = 0; q < 4; ++q) sum[q] += (double)h[i + q]; ++cnt; }
+            if (cnt) fprintf(stderr, "[gemm stamps] waves %d: prologue %.0f  loop %.0f  epilogue-loads %.0f  epilogue-stores %.0f cycles\n",
+                             cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt);
+            g_gemm_stamps = nullptr;
+            stamps.release();
+        }
+    } while (0);
+    g_gemm_dbg = 0;
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    (void)hipStreamSynchronize(s);
+    C.release(); A.release(); B.release();
+    return rc;
+}
+
+int gpmi_probe_hbm_ex(gpmi_ctx* c, int64_t bytes, int mode, int blocks, double* gbps) {
+    if (!c || !gbps || bytes < 4096 || blocks < 1 || mode < 0 || mode > 6) return fail_arg("gpmi_probe_hbm_ex: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->red.ensure(16 * 8));
+    hipStream_t s = c->stream;
+    DevBuf buf;
+    HIP_TRY(buf.ensure((size_t)bytes));
+    hipError_t e = launch_probe_write(s, buf.as<double>(), bytes / 8, mode == 4 ? 0 : mode, blocks, c->red.as<double>());
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    const int reps = 3;
+    for (int r = 0; r < reps && e == hipSuccess; ++r)
+        e = launch_probe_write(s, buf.as<double>(), bytes / 8, mode, blocks, c->red.as<double>());
+    (void)hipEventRecord(b, s);
+    hipError_t e2 = hipEventSynchronize(b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    buf.release();
+    if (e != hipSuccess) return fail_runtime(e, "probe kernel");
+    if (e2 != hipSuccess) return fail_runtime(e2, "probe sync");
+    *gbps = (double)bytes * reps / (ms * 1e-3) / 1e9;
+    return GPMI_OK;
+}
+
+int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
+    return gpmi_probe_hbm_ex(c, bytes, 0, 2048, gbps);
+}
+
+}  // extern "C"
