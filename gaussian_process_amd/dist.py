@@ -120,7 +120,8 @@ class HipBlockOps:
 class DistGP:
     """Row-block cyclic GP fit / predict over the ranks of `group` (default: WORLD)."""
 
-    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=2):
+    def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=2,
+                 force_collectives=False):
         if not dist.is_initialized():
             raise RuntimeError("DistGP needs torch.distributed (init_process_group) -- one rank per GPU")
         if nb <= 0 or nb % 128:
@@ -128,6 +129,10 @@ class DistGP:
         self.group = group
         self.rank = dist.get_rank(group)
         self.G = dist.get_world_size(group)
+        # a world of one rank needs no collective; force_collectives issues them anyway (every broadcast,
+        # all-gather and all-reduce of the multi-rank schedule, on a communicator of size 1) so that the
+        # RCCL call path can be exercised on a single GPU
+        self.coll = self.G >= 2 or bool(force_collectives)
         self.ops = ops if ops is not None else HipBlockOps(device_index)
         self.dev = self.ops.device
         self.NB = int(nb)
@@ -175,7 +180,7 @@ class DistGP:
         # X, y replicated (N*(d+1)*8 bytes); broadcast from rank 0 so every rank factors the same data
         self.X = torch.from_numpy(X).to(self.dev)
         self.y = torch.from_numpy(y).to(self.dev)
-        if G > 1:
+        if self.coll:
             dist.broadcast(self.X, src=self._src(0), group=self.group)
             dist.broadcast(self.y, src=self._src(0), group=self.group)
         self.A = self._tensor(max(self.rows, 1), self.ld)
@@ -185,7 +190,7 @@ class DistGP:
         self.recv = self._tensor(G * max(cmax, 1) * NB, NB)
         self.Lk = [self.Lkk, self._tensor(NB, NB)]
         self.Pbuf = [self._tensor(max(self.T - 1, 1) * NB, NB) for _ in range(2 if self.lookahead else 1)] \
-            if G > 1 else [None, None]
+            if self.coll else [None, None]
         self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         self.red = self._tensor(max(self.nloc, 1) + 1, 2)
         self.m = self._tensor(self.Np)
@@ -312,14 +317,14 @@ class DistGP:
             diag = A[li * NB:(li + 1) * NB, c0:c0 + NB]
             ops.potrf_block(diag, c0, self.info)
             self.Lkk.copy_(diag)
-        if G > 1:
+        if self.coll:
             dist.broadcast(self.Lkk, src=self._src(owner), group=self.group)
         ls = self._lstart(k)
         r0 = ls * NB
         m = self.rows - r0
         if m > 0:
             ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
-        if k == self.T - 1 or G == 1:
+        if k == self.T - 1 or not self.coll:
             return
         cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
         cmax = max(cnts)
@@ -378,7 +383,7 @@ class DistGP:
                 diag = A[0:NB, 0:NB]
                 ops.potrf_block(diag, 0, self.info)
                 Lk[0].copy_(diag)
-            if G > 1:
+            if self.coll:
                 dist.broadcast(Lk[0], src=self._src(0), group=self.group)
         ev_bcast = self._record("crit")
         for k in range(T):
@@ -404,7 +409,7 @@ class DistGP:
                 m = self.rows - r_rest
                 if m > 0:
                     ops.trsm_block(Lcur, A[r_rest:r_rest + m, c0:c0 + NB])
-                if k < T - 1 and G > 1:
+                if k < T - 1 and self.coll:
                     self._wait("side", ev_row)
                     self._gather_panel(k, self.Pbuf[k % 2], ls * NB)
             ev_panel = self._record("side")
@@ -412,11 +417,11 @@ class DistGP:
                 self._wait("main", ev_panel)
                 break
             with self._on("crit"):                       # queued behind the owner's potrf on this stream
-                if G > 1:
+                if self.coll:
                     dist.broadcast(Lk[(k + 1) % 2], src=self._src((k + 1) % G), group=self.group)
             ev_bcast = self._record("crit")
             self._wait("main", ev_panel)
-            if G == 1:
+            if not self.coll:
                 self._wait("main", ev_row)
             P = self._panel_view(k, self.Pbuf[k % 2])
             r1 = self._lstart(k + 1) * NB                # my rows of blocks > k+1 (and the y rows)
@@ -439,7 +444,7 @@ class DistGP:
     def _panel_view(self, k, P):
         """the panel column below block k in natural order (blocks k+1 ..)"""
         nbelow = self.T - k - 1
-        if self.G == 1:
+        if not self.coll:
             r0 = self._lstart(k) * self.NB
             return self.A[r0:r0 + nbelow * self.NB, k * self.NB:(k + 1) * self.NB]
         return P[:nbelow * self.NB]
@@ -505,7 +510,7 @@ class DistGP:
                                            self.rowmapB[off:off + ln], 128)
             self._order(first_is_side=True)               # main waits for the last panel
         # not-PD: smallest failing global column over all ranks
-        if G > 1:
+        if self.coll:
             dist.all_reduce(self.info, op=dist.ReduceOp.MIN, group=self.group)
         info = int(self.info.item())
         if info != INT64_MAX and info < self.N:
@@ -520,7 +525,7 @@ class DistGP:
             ops.logdiag_sumsq(None, 0, A[self.yrow], self.N, self.red[self.nloc])
             self.m.copy_(A[self.yrow, :self.Np])
         part = torch.stack([self.red[:max(self.nloc, 1), 0].sum(), self.red[self.nloc, 1]])
-        if G > 1:
+        if self.coll:
             allp = self._tensor(G * 2)
             dist.all_gather_into_tensor(allp, part.contiguous(), group=self.group)
             dist.broadcast(self.m, src=self._src(self.ry), group=self.group)
@@ -543,7 +548,7 @@ class DistGP:
         self.n = Xs.shape[0]
         self.n_p = _round_up(self.n, 128)
         self.Xs = torch.from_numpy(Xs).to(self.dev)
-        if self.G > 1:
+        if self.coll:
             dist.broadcast(self.Xs, src=self._src(0), group=self.group)
         self.ldv = max(self.nloc, 1) * self.NB + self.ld_pad
         self.V = self._tensor(self.n_p, self.ldv)
@@ -573,13 +578,13 @@ class DistGP:
                 li = k // G
                 blk = V[:, li * NB:(li + 1) * NB]
                 ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
-                if G > 1:
+                if self.coll:
                     Xk.copy_(blk)
-            if G > 1 and k < T - 1:
+            if self.coll and k < T - 1:
                 dist.broadcast(Xk, src=self._src(k % G), group=self.group)
 
         def xk_view(k):
-            return self.Xk[k % 2] if G > 1 else V[:, k * NB:(k + 1) * NB]
+            return self.Xk[k % 2] if self.coll else V[:, k * NB:(k + 1) * NB]
 
         if not self.lookahead:
             for k in range(T):
@@ -588,7 +593,7 @@ class DistGP:
                     break
                 ls = self._lstart(k)
                 if self.nloc - ls > 0:
-                    ops.gemm_nt(V[:, ls * NB:self.nloc * NB], self.Xk[0] if G > 1 else xk_view(k),
+                    ops.gemm_nt(V[:, ls * NB:self.nloc * NB], self.Xk[0] if self.coll else xk_view(k),
                                 A[ls * NB:self.nloc * NB, k * NB:(k + 1) * NB])
         else:
             self._order(first_is_side=False)
@@ -613,7 +618,7 @@ class DistGP:
         self.dots.zero_()
         if self.nloc:
             ops.row_dots(V, self.nloc * NB, self.m_loc, self.dots[0], self.dots[1])
-        if G > 1:
+        if self.coll:
             alld = self._tensor(G * 2 * self.n_p)
             dist.all_gather_into_tensor(alld, self.dots.view(-1), group=self.group)
         else:
@@ -659,7 +664,7 @@ class DistGP:
                 ops.gemv_t(A[r0:r1, c0:c0 + NB], aloc[r0:r1], part, scratch)
             else:
                 part.zero_()
-            if G > 1:
+            if self.coll:
                 dist.all_gather_into_tensor(allp, part, group=self.group)
             else:
                 allp.copy_(part)
@@ -676,7 +681,7 @@ class DistGP:
         send = self._tensor(cmax * NB)
         send.zero_()
         send[:self.nloc * NB].copy_(aloc[:self.nloc * NB])
-        if G > 1:
+        if self.coll:
             recv = self._tensor(G * cmax * NB)
             dist.all_gather_into_tensor(recv, send, group=self.group)
         else:

@@ -99,3 +99,16 @@ def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
 def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
     res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb, lookahead=la)
     _check(res, oracle, N, d, n)
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_on_a_world_of_one():
+    """The RCCL call path itself (backend "nccl": broadcast, all_gather_into_tensor, int64 MIN all_reduce,
+    asynchronous stream semantics over the three streams of the schedule) on the one GPU of the test box:
+    DistGP(force_collectives=True) issues every collective of the multi-rank schedule on a communicator
+    of size 1; the results must equal the run without collectives bit for bit, for every lookahead level."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_PORT=_free_port())
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "nccl_world1.py"), "3072"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "RCCL world-1 path: OK" in p.stdout
