@@ -110,15 +110,29 @@ def main():
         local_rank = 0
     backend = os.environ.get("GPMI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GPMI_BENCH_FORCE_DIST=1: run the multi-rank driver (and every RCCL collective it issues) on a world
+    # of one rank -- the distributed code path at full size on a single GPU (rehearsal, not a bench line)
+    force_dist = os.environ.get("GPMI_BENCH_FORCE_DIST") == "1"
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
         from gaussian_process_amd.dist import DistGP
-        gp = DistGP(local_rank, nb=int(os.environ.get("GPMI_DIST_NB", "512")),
-                    lookahead=int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2")))
+        # block rows: as large as leaves every rank >= 8 blocks (balance of the shrinking trailing matrix),
+        # capped at 2048 -- measured with the multi-rank driver on one rank at N=65536: nb 512 / 1024 / 2048
+        # = 2.01 / 1.92 / 1.87 s (the update GEMM is more efficient at larger depth, and there are fewer steps)
+        nb_auto = 256
+        while nb_auto < 2048 and N // (2 * nb_auto) >= 8 * max(world, 1):
+            nb_auto *= 2
+        gp = DistGP(local_rank, nb=int(os.environ.get("GPMI_DIST_NB", str(nb_auto))),
+                    lookahead=int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2")), force_collectives=force_dist)
         gp.set_train(X, y)
         gp.set_test(Xs)
 
@@ -153,13 +167,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lml, mu, var = step()
-        if world == 1:
+        if world == 1 and not force_dist:
             tf = ctx.timers()
             for k, v in tf.items():
                 stage[k] = stage.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -183,9 +197,11 @@ def main():
                        "partition": "single GPU" if world == 1 else "row-block cyclic x%d" % world},
             "lml": float(lml),
         }
-        if world > 1 and stage:
+        if (world > 1 or force_dist) and stage:
             out["stages_ms"] = stage            # last step, rank 0: fit / predict wall
-        if world == 1 and stage:
+            if force_dist:
+                out["config"]["partition"] = "multi-rank driver forced on one rank (RCCL communicator of size 1)"
+        if world == 1 and stage and not force_dist:
             k = args.steps
             trail_ms = stage.get("chol_trail", 0.0) / k
             trail_flops = stage.get("trail_flops", 0.0) / k
@@ -215,10 +231,10 @@ def main():
                                      "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                      "frac": kbytes / (kb * 1e-3) / 1e9 / PEAK_HBM_GBPS,
                                      "bytes": kbytes, "note": "lower tiles incl. diagonal"}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not force_dist:
             out["cpu_baseline"] = cpu_baseline(d, n)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
