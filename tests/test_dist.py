@@ -95,7 +95,8 @@ def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
                                                 (1, 1300, 8, 100, 256, 1),
                                                 (2, 6144, 8, 128, 256, 1),    # large enough for the LDS-DMA GEMM + row map
                                                 (1, 1300, 8, 100, 256, 2), (2, 1500, 8, 200, 256, 2),
-                                                (3, 2100, 8, 130, 128, 2), (2, 6144, 8, 128, 256, 2)])
+                                                (3, 2100, 8, 130, 128, 2), (2, 6144, 8, 128, 256, 2),
+                                                (2, 6144, 8, 128, 2048, 2), (3, 6144, 8, 128, 1024, 2)])   # the bench's block rows
 def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
     res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb, lookahead=la)
     _check(res, oracle, N, d, n)
