@@ -81,6 +81,25 @@ int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const doub
     return GPMI_OK;
 }
 
+// The same with a host copy of the row map (row_bands entries): the launcher then enumerates only the
+// supertiles that hold live tiles (a rectangle half full of skipped workgroups runs 15 % slower).
+int gpmi_dev_gemm_nt_rowmap_host(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                                 const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                                 const int32_t* row_ncols_dev, const int32_t* row_ncols_host, int64_t row_bands,
+                                 int64_t row_block_rows) {
+    if (!C_dev || !A_dev || !B_dev || !row_ncols_dev || !row_ncols_host) return fail_arg("gpmi_dev_gemm_nt_rowmap_host: null pointer");
+    if (M < 0 || N < 0 || K < 0 || M % TILE || N % IB || K % 16 || ldc % 2 || lda % 2 || ldb % 2 ||
+        row_block_rows <= 0 || row_block_rows % TILE || row_bands * row_block_rows < M)
+        return fail_arg("gpmi_dev_gemm_nt_rowmap_host: M%128, N%64, K%16, row_block_rows%128 must be 0 and the map must cover M");
+    GemmArgs g;
+    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = 0; g.diag_off = 0;
+    g.row_ncols = row_ncols_dev; g.row_block_tiles = (int)(row_block_rows / TILE);
+    g.row_ncols_host = row_ncols_host; g.row_bands = (int)row_bands;
+    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
+    return GPMI_OK;
+}
+
 int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
                            int64_t nx, double* out2_dev) {
     if (!out2_dev) return fail_arg("gpmi_dev_logdiag_sumsq: null output");

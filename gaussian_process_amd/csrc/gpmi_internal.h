@@ -27,6 +27,10 @@ struct GemmArgs {
     // row blocks reach different distances to the right); device pointer or null
     const int32_t* row_ncols = nullptr;
     int row_block_tiles = 1;
+    // optional host copy of row_ncols (row_bands entries): lets the launcher enumerate only the
+    // supertiles that hold live tiles instead of the whole rectangle
+    const int32_t* row_ncols_host = nullptr;
+    int row_bands = 0;
     int role = 0;   // 1: Cholesky trailing update (launched under its own kernel symbol)
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);

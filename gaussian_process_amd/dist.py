@@ -90,7 +90,15 @@ class HipBlockOps:
         check(self.lib.gpmi_dev_gemm_nt(self._stream(), self._p(Cm), self._ld(Cm), self._p(A), self._ld(A),
                                         self._p(B), self._ld(B), Cm.shape[0], Cm.shape[1], A.shape[1], 0, 0))
 
-    def gemm_nt_rowmap(self, Cm, A, B, row_ncols, row_block_rows):
+    def gemm_nt_rowmap(self, Cm, A, B, row_ncols, row_block_rows, row_ncols_host=None):
+        """row_ncols_host: the same map as a contiguous int32 NumPy array -- only the supertiles with live
+        tiles are then launched"""
+        if row_ncols_host is not None:
+            check(self.lib.gpmi_dev_gemm_nt_rowmap_host(
+                self._stream(), self._p(Cm), self._ld(Cm), self._p(A), self._ld(A), self._p(B), self._ld(B),
+                Cm.shape[0], Cm.shape[1], A.shape[1], C.c_void_p(row_ncols.data_ptr()),
+                C.c_void_p(row_ncols_host.ctypes.data), row_ncols_host.shape[0], row_block_rows))
+            return
         check(self.lib.gpmi_dev_gemm_nt_rowmap(self._stream(), self._p(Cm), self._ld(Cm), self._p(A), self._ld(A),
                                                self._p(B), self._ld(B), Cm.shape[0], Cm.shape[1], A.shape[1],
                                                C.c_void_p(row_ncols.data_ptr()), row_block_rows))
@@ -208,6 +216,7 @@ class DistGP:
             tabs.append(t)
         flat = [v for t in tabs for v in t] or [0]
         self.rowmap = torch.tensor(flat, dtype=torch.int32, device=self.dev)
+        self.rowmap_h = np.ascontiguousarray(flat, dtype=np.int32)
         self.rowmap_off = offs
         self.rowmap_len = [len(t) for t in tabs]
         # lookahead part (b) of step k: my rows of blocks > k+1 update columns from block k+2 on
@@ -223,6 +232,7 @@ class DistGP:
             tabs.append(t)
         flat = [v for t in tabs for v in t] or [0]
         self.rowmapB = torch.tensor(flat, dtype=torch.int32, device=self.dev)
+        self.rowmapB_h = np.ascontiguousarray(flat, dtype=np.int32)
         self.rowmapB_off = offs
         self.rowmapB_len = [len(t) for t in tabs]
         # critical-path-first schedule: the diagonal block of block row k+2 is updated ahead of part (b)
@@ -235,6 +245,7 @@ class DistGP:
                 t[:bands] = [0] * bands
             flatC += t
         self.rowmapC = torch.tensor(flatC or [0], dtype=torch.int32, device=self.dev)
+        self.rowmapC_h = np.ascontiguousarray(flatC or [0], dtype=np.int32)
         self.have_factor = False
         self.have_test = False
 
@@ -437,7 +448,7 @@ class DistGP:
             if k + 2 < T and m1 > 0:                     # (b) the remaining columns
                 off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
                 ops.gemm_nt_rowmap(A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], P[NB:],
-                                   self.rowmapC[off:off + ln], 128)
+                                   self.rowmapC[off:off + ln], 128, self.rowmapC_h[off:off + ln])
         self._wait("main", ev_bcast)
         self._wait("main", self._record("crit"))
 
@@ -485,7 +496,8 @@ class DistGP:
                 if m > 0:
                     off, ln = self.rowmap_off[k], self.rowmap_len[k]
                     ops.gemm_nt_rowmap(A[r0:r0 + m, (k + 1) * NB:self.Np], A[r0:r0 + m, k * NB:(k + 1) * NB],
-                                       self._panel_view(k, self.Pbuf[0]), self.rowmap[off:off + ln], 128)
+                                       self._panel_view(k, self.Pbuf[0]), self.rowmap[off:off + ln], 128,
+                                       self.rowmap_h[off:off + ln])
         else:
             self._order(first_is_side=False)              # side waits for the K build
             with self._side():
@@ -507,7 +519,7 @@ class DistGP:
                     if m1 > 0:
                         off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
                         ops.gemm_nt_rowmap(A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], P[NB:],
-                                           self.rowmapB[off:off + ln], 128)
+                                           self.rowmapB[off:off + ln], 128, self.rowmapB_h[off:off + ln])
             self._order(first_is_side=True)               # main waits for the last panel
         # not-PD: smallest failing global column over all ranks
         if self.coll:

@@ -226,6 +226,12 @@ int gpmi_dev_gemm_nt(void* stream, double* C_dev, int64_t ldc, const double* A_d
 int gpmi_dev_gemm_nt_rowmap(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
                             const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
                             const int32_t* row_ncols_dev, int64_t row_block_rows);
+/* the same with a host copy of the row map (row_bands entries covering M): only the supertiles that hold
+ * live tiles are launched */
+int gpmi_dev_gemm_nt_rowmap_host(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                                 const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                                 const int32_t* row_ncols_dev, const int32_t* row_ncols_host, int64_t row_bands,
+                                 int64_t row_block_rows);
 /* out2[0] = sum_{i<n} log(A[i][i]) (skipped if A_dev is NULL), out2[1] = sum_{i<nx} x[i]^2
  * (skipped if x_dev is NULL): the per-rank pieces of the log-marginal-likelihood */
 int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,

@@ -72,7 +72,7 @@ class NumpyBlockOps:
         c = self._a(Cm)
         c -= self._a(A) @ self._a(B).T
 
-    def gemm_nt_rowmap(self, Cm, A, B, row_ncols, row_block_rows):
+    def gemm_nt_rowmap(self, Cm, A, B, row_ncols, row_block_rows, row_ncols_host=None):
         c, a, b = self._a(Cm), self._a(A), self._a(B)
         nc = row_ncols.numpy()
         for q in range(c.shape[0] // row_block_rows):
