@@ -126,8 +126,8 @@ def main():
             dist.init_process_group(backend)
         from gaussian_process_amd.dist import DistGP
         # block rows: as large as leaves every rank >= 8 blocks (balance of the shrinking trailing matrix),
-        # capped at 2048 -- measured with the multi-rank driver on one rank at N=65536: nb 512 / 1024 / 2048
-        # = 2.01 / 1.92 / 1.87 s (the update GEMM is more efficient at larger depth, and there are fewer steps)
+        # capped at 2048 -- measured with the multi-rank driver on one rank at N=65536: nb 1024 / 2048
+        # = 1.86 / 1.83 s (the update GEMM is more efficient at larger depth, and there are fewer steps)
         nb_auto = 256
         while nb_auto < 2048 and N // (2 * nb_auto) >= 8 * max(world, 1):
             nb_auto *= 2
