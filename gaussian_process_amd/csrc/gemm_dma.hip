@@ -33,7 +33,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GPMI_LDS __attribute__((address_space(3)))
 #define GPMI_GLB __attribute__((address_space(1)))
 
-constexpr int DMA_MAX_SM = 64;
+constexpr int DMA_MAX_SM = 128;   // supertile rows a staircase launch can describe (M up to 131072 at S = 8)
 
 struct GemmDmaDev {
     double* C;
