@@ -113,3 +113,38 @@ def test_rccl_collectives_on_a_world_of_one():
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "RCCL world-1 path: OK" in p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,band_rows", [(2048, 4096, 256, 128), (3072, 6144, 512, 256), (512, 1024, 128, 128)])
+def test_row_map_update_live_supertiles_only(M, N, K, band_rows):
+    """gpmi_dev_gemm_nt_rowmap_host (only the supertiles with live tiles are launched) against the plain
+    row-map launch (whole rectangle) and NumPy, on staircases like a rank's stacked row blocks: bitwise
+    equal to each other, columns beyond a band's reach untouched."""
+    import torch
+    from gaussian_process_amd.dist import HipBlockOps
+    ops = HipBlockOps(0)
+    rng = np.random.default_rng(M + K)
+    nb = M // band_rows
+    reach = np.minimum(N, 384 + 2 * band_rows * np.arange(nb)).astype(np.int32)     # slope 2, like 2 ranks
+    reach[-1] = N                                                                  # the y rows reach everything
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    C0 = rng.standard_normal((M, N))
+    want = C0.copy()
+    for b in range(nb):
+        rows = slice(b * band_rows, (b + 1) * band_rows)
+        live = -(-int(reach[b]) // 128) * 128                                      # whole 128-column tiles
+        live = min(live, N)
+        want[rows, :live] -= A[rows] @ B[:live].T
+    dev = torch.device("cuda", 0)
+    Ad, Bd = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev)
+    rm = torch.from_numpy(reach).to(dev)
+    outs = []
+    for host in (None, reach):
+        Cd = torch.from_numpy(C0).to(dev)
+        ops.gemm_nt_rowmap(Cd, Ad, Bd, rm, band_rows, host)
+        torch.cuda.synchronize()
+        outs.append(Cd.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.allclose(outs[1], want, rtol=0, atol=1e-10 * np.abs(want).max())
