@@ -586,7 +586,7 @@ int gpmi_lml_batch(gpmi_ctx* c, const double* triples, int64_t T, double* lml_ou
     HIP_TRY(hipSetDevice(c->device));
     const int64_t Np = round_up(c->N, TILE);
     // two lanes; more do not help (measured, 12 triples: N = 512 0.45 / 0.24 / 0.38 / 0.31 ms per triple with
-    // 1 / 2 / 3 / 4 lanes, unchanged with GPU_MAX_HW_QUEUES=8: the host threads contend on the launch path)
+    // 1 / 2 / 3 / 4 lanes, unchanged with GPU_MAX_HW_QUEUES=8)
     int L = c->lanes ? c->lanes : (Np <= 32768 ? 2 : 1);
     L = (int)std::min<int64_t>(L, std::max<int64_t>(T, 1));
     while ((int)c->lane_ctx.size() < L - 1) {
