@@ -2,17 +2,22 @@
 """Headline benchmark: GP fit + predict at N=65536, d=8, n=4096 test points, fp64.
 
 One "step" = the whole hot path on inputs already resident in HBM:
-  K(X,X)+s*I build -> blocked Cholesky (forward solve folded in) -> LML
+  K(X,X)+s*I build -> blocked Cholesky (forward solve folded in) -> LML -> backward solve (alpha)
   -> K(X*,X) build -> v = L^-1 K_s sweep -> predictive mean / variance.
 value = algorithmic fp64 flops of that path (N^3/3 + N^2/2 + N/6 for the Cholesky,
 N^2*n for the triangular solve of K_s) / wall time, whole job, in TFLOP/s.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size N] [--dim d] [--ntest n]
-For --gpus > 1 launch with torch.distributed.run (one rank per GPU, RCCL).
+
+--gpus N > 1: one process per GPU over RCCL.  Under torch.distributed.run (RANK / WORLD_SIZE in the
+environment) this process is one rank; started plainly, it spawns the N ranks itself as fresh child
+processes BEFORE anything touches the GPU, waits for them and exits with the worst of their codes.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +33,18 @@ try:
 except (OSError, KeyError, ValueError):
     pass
 
-PEAK_FP64_MFMA_TFLOPS = 78.6     # vendor dense fp64 matrix peak, MI355X
+# nominal MI355X peaks; `peaks_probe` in the output is what this
+# box sustains on bare probe kernels in this run
+PEAK_FP64_MFMA_TFLOPS = 78.6     # 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0
+# north_star targets
+TARGET_TRAIL_FRAC = 0.40
+TARGET_KBUILD_FRAC = 0.60
+TARGET_SPEEDUP_8 = 6.0
+TARGET_MEAN_TOL = 1e-8
+# the committed rocprofv3 PMC passes `roofline.traffic` is read from (same command, N=65536 n=4096)
+TRAFFIC_PROFILE = os.path.join("profiles", "r02_roofline_traffic.json")
+TRAFFIC_PROFILE_FALLBACK = os.path.join("profiles", "r01d_roofline_traffic.json")
 
 
 def algorithmic_flops(N, n):
@@ -38,43 +53,108 @@ def algorithmic_flops(N, n):
     return chol + trsm
 
 
+def _blas_info():
+    threads, desc = os.cpu_count(), "unknown"
+    try:
+        from threadpoolctl import threadpool_info
+        blas = [i for i in threadpool_info() if i.get("user_api") == "blas"]
+        if blas:
+            threads = max(i.get("num_threads") or 1 for i in blas)
+            desc = "; ".join("%s %s (%s)" % (i.get("internal_api"), i.get("version"), i.get("threading_layer")) for i in blas)
+    except Exception:
+        pass
+    return threads, desc
+
+
 def cpu_baseline(d, n_test):
-    """The oracle (a port of the reference's NumPy path with true triangular solves and a
-    C kernel-matrix build) timed on this host's cores on a bounded sample of the workload."""
+    """BASELINE.md section 3, on this host's cores, bounded to about half a minute of CPU work by default:
+      * reference-faithful variant (broadcast (N,d,N) kernel build, np.linalg.cholesky, three LU np.linalg.solve
+        calls on the triangular factor: GP_regression.py:18-19,138-144) at N = 2048 and 4096; N = 8192 only with
+        GPMI_CPU_BASELINE_FULL=1 (else projected from 4096 and labelled so);
+      * memory-feasible variant (the oracle: C kernel build with the reference's per-element arithmetic,
+        scipy Cholesky + true triangular solves) at N = 16384 (32768 with GPMI_CPU_BASELINE_FULL=1), stage-timed,
+        and an N^3 / N^2 extrapolation of those stages to the bench size, labelled "extrapolated".
+    `value` is the measured feasible-variant rate; nothing here is measured at the headline N."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gp_oracle as O
     lib = os.path.join(ROOT, "oracle", "build", "librbf_oracle.so")
     if not os.path.exists(lib):
-        import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
-    Ns = int(os.environ.get("GPMI_CPU_BASELINE_N", "12288"))
+    full = os.environ.get("GPMI_CPU_BASELINE_FULL") == "1"
+    ell = 2.0 * np.sqrt(d / 8.0)
+    threads, blas = _blas_info()
+
+    faithful = []
+    nf = 1024
+    for Nf in (2048, 4096, 8192):
+        if Nf == 8192 and not full:
+            t4 = faithful[-1]["seconds"]
+            faithful.append({"N": Nf, "n_test": nf, "seconds": None, "projected_seconds": t4 * 4.7,
+                             "note": "not run in the default (bounded) bench: projected from N=4096 with the "
+                                     "N=4096 -> 8192 ratio measured in BASELINE.md section 2 (42.8 / 9.12); "
+                                     "GPMI_CPU_BASELINE_FULL=1 runs it"})
+            continue
+        Xf, yf, Xsf = O.synthetic_problem(Nf, d, nf)
+        t1 = time.perf_counter()
+        O.posterior(Xf, Xsf, yf, 1.0, ell, 5e-4)
+        faithful.append({"N": Nf, "n_test": nf, "seconds": time.perf_counter() - t1})
+
+    Ns = int(os.environ.get("GPMI_CPU_BASELINE_N", "32768" if full else "16384"))
     X, y, Xs = O.synthetic_problem(Ns, d, n_test)
+    stages = {}
     t0 = time.perf_counter()
-    O.fit_predict_feasible(X, Xs, y, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
+    O.fit_predict_feasible(X, Xs, y, 1.0, ell, 5e-4, timings=stages)
     dt = time.perf_counter() - t0
-    threads = os.cpu_count()
-    try:
-        from threadpoolctl import threadpool_info
-        th = [i.get("num_threads") for i in threadpool_info() if i.get("user_api") == "blas"]
-        if th:
-            threads = max(th)
-    except Exception:
-        pass
-    # the reference-faithful algorithm (broadcast (N,d,N) kernel build, np.linalg.cholesky, three LU
-    # np.linalg.solve calls on the triangular factor: GP_regression.py:18-19,138-144) at the largest
-    # size its O(N^2 d) temporaries allow in a bounded time
-    Nf, nf = 4096, 1024
-    Xf, yf, Xsf = O.synthetic_problem(Nf, d, nf)
-    t1 = time.perf_counter()
-    O.posterior(Xf, Xsf, yf, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
-    dtf = time.perf_counter() - t1
+
+    def extrapolate(N):
+        r = N / float(Ns)
+        return (stages.get("kbuild", 0.0) * r ** 2 + stages.get("chol", 0.0) * r ** 3 + stages.get("trsv", 0.0) * r ** 2 +
+                stages.get("ks", 0.0) * r + stages.get("trsm", 0.0) * r ** 2 + stages.get("meanvar", 0.0) * r)
+    N_head = 65536
+    ext = extrapolate(N_head)
     return {"value": algorithmic_flops(Ns, n_test) / dt / 1e12, "unit": "TFLOP/s", "cores": threads,
-            "kind": "port", "seconds": dt,
-            "reference_faithful": {"N": Nf, "n_test": nf, "seconds": dtf,
-                                   "note": "broadcast RBF + cholesky + 3 LU solves, as the reference issues them"},
-            "sample": "oracle fit+predict at N=%d d=%d n=%d (same generator and hyper-parameters; "
-                      "the reference's own (N,d,N) broadcast cannot run beyond N~8192)" % (Ns, d, n_test)}
+            "kind": "port", "seconds": dt, "blas": blas, "os_cpu_count": os.cpu_count(),
+            "stages_s": stages,
+            "reference_faithful": faithful,
+            "reference_faithful_note": "broadcast RBF + np.linalg.cholesky + 3 LU np.linalg.solve, as the reference "
+                                       "issues them; d=%d, n_test=%d; cannot run beyond N~8192 (O(N^2 d) temporaries)" % (d, nf),
+            "extrapolated": {"N": N_head, "n_test": n_test, "seconds": ext,
+                             "tflops": algorithmic_flops(N_head, n_test) / ext / 1e12,
+                             "label": "extrapolated", "how": "stage times at N=%d scaled by N^3 (Cholesky), N^2 (kernel "
+                                      "build, TRSV, TRSM at fixed n) and N (K_s, mean/variance); not measured: two "
+                                      "8*N^2-byte matrices at N=65536 need >= 70 GB of host RAM" % Ns},
+            "sample": "oracle (memory-feasible restatement) fit+predict at N=%d d=%d n=%d, same generator and "
+                      "hyper-parameters as the GPU run" % (Ns, d, n_test)}
+
+
+def spawn_ranks(n):
+    """Parent of a plain `python bench.py --gpus n`: start the n ranks as fresh children (the parent never touches
+    the GPU), wait, return the worst exit code.  A failed rank takes the others down after a grace period."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        for p in procs:
+            rc = p.poll()
+            if rc not in (None, 0) and failed_at is None:
+                failed_at = time.time()
+        if failed_at is not None and time.time() - failed_at > 30:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    for p in procs:
+        rc = p.wait()
+        if rc != 0:
+            worst = rc if rc > 0 else 1
+    return worst
 
 
 def main():
@@ -88,6 +168,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))      # before torch / HIP are imported in this process
+    echo = os.environ.get("GPMI_BENCH_SPAWN_ECHO")
+    if echo:                                  # tests/test_dist.py: what a spawned rank sees, no GPU needed
+        print(json.dumps({"rank": int(os.environ.get("RANK", "0")), "world": int(os.environ.get("WORLD_SIZE", "1")),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "addr": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT")}), flush=True)
+        sys.exit(3 if echo == "fail" + os.environ.get("RANK", "0") else 0)
+
     import numpy as np
     import torch
 
@@ -95,8 +184,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     N, d, n = args.size, args.dim, args.ntest
     ell, sigma, s = 2.0 * np.sqrt(d / 8.0), 1.0, 5e-4
 
@@ -118,7 +206,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29655")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if world > 1 or force_dist:
+    multi = world > 1 or force_dist
+    if multi:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -131,15 +220,17 @@ def main():
         nb_auto = 256
         while nb_auto < 2048 and N // (2 * nb_auto) >= 8 * max(world, 1):
             nb_auto *= 2
-        gp = DistGP(local_rank, nb=int(os.environ.get("GPMI_DIST_NB", str(nb_auto))),
+        nb_used = int(os.environ.get("GPMI_DIST_NB", str(nb_auto)))
+        gp = DistGP(local_rank, nb=nb_used,
                     lookahead=int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2")), force_collectives=force_dist)
         gp.set_train(X, y)
         gp.set_test(Xs)
 
         def step():
             lml = gp.factorize(sigma, ell, s)
+            alpha = gp.alpha()
             mu, var = gp.predict_resident(want_sd=False)
-            return lml, mu, var
+            return lml, mu, var, alpha
 
         def barrier():
             dist.barrier()
@@ -153,8 +244,9 @@ def main():
 
         def step():
             lml = ctx.factorize(sigma, ell, s)
+            alpha = ctx.alpha()
             mu, var = ctx.predict_resident(want_sd=False)
-            return lml, mu, var
+            return lml, mu, var, alpha
 
         def barrier():
             torch.cuda.synchronize()
@@ -166,24 +258,31 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        lml, mu, var = step()
-        if world == 1 and not force_dist:
+        lml, mu, var, alpha = step()
+        if not multi:
             tf = ctx.timers()
             for k, v in tf.items():
                 stage[k] = stage.get(k, 0.0) + v
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1 or force_dist:
+    per_rank = None
+    if multi:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         stage = timers_fn()
+        mine = torch.tensor([stage.get("fit", 0.0), stage.get("alpha", 0.0), stage.get("predict", 0.0)],
+                            device="cuda", dtype=torch.float64)
+        allr = torch.empty(world * 3, device="cuda", dtype=torch.float64)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [{"rank": r, "fit_ms": float(v[0]), "alpha_ms": float(v[1]), "predict_ms": float(v[2])}
+                    for r, v in enumerate(allr.view(world, 3).cpu().numpy())]
     ms_per_step = dt / args.steps * 1e3
     flops = algorithmic_flops(N, n)
     value = flops / (dt / args.steps) / 1e12
 
     if rank == 0:
-        assert np.all(np.isfinite(mu)) and np.isfinite(lml)
+        assert np.all(np.isfinite(mu)) and np.isfinite(lml) and np.all(np.isfinite(alpha))
         out = {
             "metric": BASELINE_METRIC,
             "value": value, "unit": "TFLOP/s", "seconds": dt / args.steps,
@@ -197,44 +296,75 @@ def main():
                        "partition": "single GPU" if world == 1 else "row-block cyclic x%d" % world},
             "lml": float(lml),
         }
-        if (world > 1 or force_dist) and stage:
-            out["stages_ms"] = stage            # last step, rank 0: fit / predict wall
+        targets = {}
+        if multi:
+            out["rccl_ranks"] = dist.get_world_size()
+            out["backend"] = backend
+            out["config"]["block_rows"] = nb_used
+            out["stages_ms"] = stage            # last step, rank 0: fit / alpha / predict wall
+            out["per_rank_ms"] = per_rank
             if force_dist:
                 out["config"]["partition"] = "multi-rank driver forced on one rank (RCCL communicator of size 1)"
-        if world == 1 and stage and not force_dist:
+            targets["speedup_8gpu"] = {"target": TARGET_SPEEDUP_8, "note": "value at n_gpus=8 / value at n_gpus=1; "
+                                       "computed by the driver from the per-N lines"}
+        if not multi and stage:
             k = args.steps
             trail_ms = stage.get("chol_trail", 0.0) / k
             trail_flops = stage.get("trail_flops", 0.0) / k
             launches = stage.get("trail_launches", 0.0) / k
             ach = trail_flops / (trail_ms * 1e-3) / 1e12 if trail_ms > 0 else 0.0
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "r01d_roofline_traffic.json")
-            if os.path.exists(tpath) and N == 65536 and n == 4096:
+            traffic, traffic_src = None, None
+            if N == 65536 and n == 4096:
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same
                 # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/rocpd_extract.py traffic)
-                traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+                for rel in (TRAFFIC_PROFILE, TRAFFIC_PROFILE_FALLBACK):
+                    tpath = os.path.join(ROOT, rel)
+                    if os.path.exists(tpath):
+                        tj = json.load(open(tpath))
+                        traffic = tj.get("traffic_bytes_per_launch")
+                        traffic_src = {"file": rel, "git": tj.get("git"), "measured": "separate rocprofv3 --pmc passes, "
+                                       "not in this run"}
+                        break
             out["roofline"] = {
                 "kernel": "chol_trailing_update_dma_kernel (Cholesky trailing update: 128x128 tile, 8 waves x 2x4 "
                           "v_mfma_f64_16x16x4_f64, LDS-DMA staging)",
                 "bound": "mfma", "achieved": ach, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "bytes/launch",
+                "traffic_source": traffic_src,
                 "launches_per_step": launches,
                 "flops_per_launch": trail_flops / launches if launches else 0.0,
                 "avg_launch_ms": trail_ms / launches if launches else 0.0}
             out["stages_ms"] = {kk: vv / k for kk, vv in stage.items() if not kk.startswith("trail_")}
+            targets["trailing_update_mfma_frac"] = {"target": TARGET_TRAIL_FRAC, "achieved": ach / PEAK_FP64_MFMA_TFLOPS,
+                                                    "met": ach / PEAK_FP64_MFMA_TFLOPS >= TARGET_TRAIL_FRAC}
             kb = stage.get("kbuild", 0.0) / k
             if kb > 0:
                 Np = (N + 127) // 128 * 128
                 T = Np // 128
                 kbytes = 8.0 * 128 * 128 * T * (T + 1) / 2 + 16.0 * N * d
+                frac = kbytes / (kb * 1e-3) / 1e9 / PEAK_HBM_GBPS
                 out["kbuild_hbm"] = {"bound": "hbm", "achieved": kbytes / (kb * 1e-3) / 1e9,
-                                     "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                                     "frac": kbytes / (kb * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                                     "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": frac,
                                      "bytes": kbytes, "note": "lower tiles incl. diagonal"}
+                targets["kbuild_hbm_frac"] = {"target": TARGET_KBUILD_FRAC, "achieved": frac, "met": frac >= TARGET_KBUILD_FRAC}
+            al = stage.get("alpha", 0.0) / k
+            if al > 0:
+                abytes = 8.0 * N * (N + 1) / 2
+                out["alpha_hbm"] = {"bound": "hbm", "achieved": abytes / (al * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
+                                    "unit": "GB/s", "frac": abytes / (al * 1e-3) / 1e9 / PEAK_HBM_GBPS, "bytes": abytes,
+                                    "ms": al, "note": "a5: backward solve L^T alpha = m reads the triangle once"}
+            # what this box sustains on bare probe kernels (nominal peaks above are what fractions are priced against)
+            try:
+                tf_probe, ghz, _ = ctx.probe_mfma_f64_ex(2, 16, 2048)
+                out["peaks_probe"] = {"fp64_mfma_tflops": tf_probe, "shader_clock_ghz": ghz,
+                                      "hbm_write_gbps": ctx.probe_hbm_write(1 << 30)}
+            except Exception as e:      # a probe must never cost the bench line
+                out["peaks_probe"] = {"error": str(e)}
+        out["targets"] = targets
         if world == 1 and not args.no_cpu_baseline and not force_dist:
             out["cpu_baseline"] = cpu_baseline(d, n)
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dist:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -320,9 +320,6 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
     gemm_nt_dma_body<2, false>(p);
 }
 
-unsigned long long* g_gemm_stamps = nullptr;
-int g_gemm_dma_waves = 8;   // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
-
 bool gemm_dma_eligible(const GemmArgs& a) {
     return a.mode == 0 && a.N % 128 == 0 && a.M % 128 == 0 && a.K % 16 == 0 && a.K >= 32;
 }
@@ -369,18 +366,22 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     p.logS = (p.S == 8) ? 3 : (p.S == 4) ? 2 : (p.S == 2) ? 1 : 0;
     const int nblocks = ((p.nsuper + 7) / 8) * 8 * p.S * p.S;
     constexpr size_t lds = (size_t)DMA_STAGES * DMA_STAGE_SLOTS * 16;
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_dma_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)chol_trailing_update_dma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    p.dbg = g_gemm_dbg & 0xff;
-    p.stamps = g_gemm_stamps;
-    if (g_gemm_dma_waves == 8) {
+    static PerDeviceOnce once;
+    const hipError_t ea = once.run([&]() -> hipError_t {
+        const void* fns[] = {(const void*)gemm_nt_dma_kernel<4, false>, (const void*)gemm_nt_dma_kernel<4, true>,
+                             (const void*)gemm_nt_dma_kernel<2, false>, (const void*)gemm_nt_dma_kernel<2, true>,
+                             (const void*)chol_trailing_update_dma_kernel};
+        for (const void* f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    });
+    if (ea != hipSuccess) return ea;
+    const Tuning& tn = tuning();
+    p.dbg = tn.gemm_dbg & 0xff;
+    p.stamps = tn.gemm_stamps;
+    if (tn.gemm_dma_waves == 8) {
         if (p.dbg) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, true>), dim3(nblocks), dim3(512), lds, s, p);
         else if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_dma_kernel, dim3(nblocks), dim3(512), lds, s, p);
         else hipLaunchKernelGGL((gemm_nt_dma_kernel<2, false>), dim3(nblocks), dim3(512), lds, s, p);

@@ -227,8 +227,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmDev p) {
     }
 }
 
-int g_gemm_dbg = 0;
-
 static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
     p.C = a.C; p.A = a.A; p.B = a.B;
     p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
@@ -255,15 +253,13 @@ static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
     }
     p.logS = (p.S == 8) ? 3 : (p.S == 4) ? 2 : (p.S == 2) ? 1 : 0;
     nblocks = ((p.nsuper + 7) / 8) * 8 * p.S * p.S;
-    p.dbg = g_gemm_dbg;
+    p.dbg = tuning().gemm_dbg;
 }
-
-int g_gemm_use_dma = 1;
-int g_gemm_small_tiles = 1;
 
 bool gemm_nt_routes_dma(const GemmArgs& a) {
     // ablation bits >= 256 select the DMA kernel's ablations (low byte passed on)
-    return g_gemm_use_dma && (!g_gemm_dbg || g_gemm_dbg >= 256) && gemm_dma_eligible(a) &&
+    const Tuning& tn = tuning();
+    return tn.gemm_use_dma && (!tn.gemm_dbg || tn.gemm_dbg >= 256) && gemm_dma_eligible(a) &&
            (a.M / 128) * (a.N / 128) >= 256;
 }
 
@@ -273,17 +269,19 @@ hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
     if (gemm_nt_routes_dma(a)) return launch_gemm_nt_dma(s, a);
     GemmDev p;
     int nblocks;
-    static bool attr = false;
-    if (!attr) {
+    static PerDeviceOnce once;
+    const hipError_t ea = once.run([&]() -> hipError_t {
         constexpr int big = 2 * (KP * 128 + KP * 128) * 16;
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
-        attr = true;
-    }
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)gemm_nt_kernel<4, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big);
+    });
+    if (ea != hipSuccess) return ea;
+    const Tuning& tn = tuning();
     // few tiles: one 128 x 128 tile keeps a CU busy for 1.8 us per 64 of K while the rest of the
     // chip idles -- 64 x 64 tiles finish 4x sooner (panel-internal updates, diagonal blocks)
     const int64_t tiles128 = (a.M / 128) * ((a.N + 127) / 128);
-    if (g_gemm_small_tiles && !g_gemm_dbg && tiles128 < 128) {
+    if (tn.gemm_small_tiles && !tn.gemm_dbg && tiles128 < 128) {
         plan(a, 64, 64, p, nblocks);
         constexpr size_t lds = 2 * (KP * 64 + KP * 64) * 16;
         hipLaunchKernelGGL((gemm_nt_kernel<2, 2, false>), dim3(nblocks), dim3(256), lds, s, p);

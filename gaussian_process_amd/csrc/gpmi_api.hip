@@ -19,6 +19,12 @@ using namespace gpmi;
 
 namespace gpmi {
 thread_local std::string g_err;
+
+static const Tuning k_default_tuning;
+static thread_local const Tuning* t_tuning = nullptr;
+const Tuning& tuning() { return t_tuning ? *t_tuning : k_default_tuning; }
+TuneScope::TuneScope(const Tuning* t) : prev(t_tuning) { t_tuning = t; }
+TuneScope::~TuneScope() { t_tuning = prev; }
 }
 
 extern "C" {
@@ -65,7 +71,7 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->X, &c->y, &c->A, &c->info, &c->red, &c->Xs, &c->V, &c->P, &c->vec, &c->dense,
-                       &c->U, &c->Kn, &c->gpart})
+                       &c->U, &c->Kn, &c->gpart, &c->cov_a, &c->cov_b, &c->cov_out})
         b->release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -93,17 +99,19 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
     } else if (!strcmp(name, "ramp")) {
         c->ramp = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_small_tiles")) {
-        g_gemm_small_tiles = value ? 1 : 0;
+        c->tune.gemm_small_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "trsm_wave")) {
-        g_trsm_wave = value ? 1 : 0;
+        c->tune.trsm_wave = value ? 1 : 0;
+    } else if (!strcmp(name, "panel_fused")) {
+        c->tune.panel_fused = value ? 1 : 0;
     } else if (!strcmp(name, "rbf_blocks")) {
         if (value < 1 || value > (1 << 24)) return fail_arg("rbf_blocks must be in 1..2^24");
-        g_rbf_blocks = (int)value;
+        c->tune.rbf_blocks = (int)value;
     } else if (!strcmp(name, "gemm_dma_waves")) {
         if (value != 4 && value != 8) return fail_arg("gemm_dma_waves must be 4 or 8");
-        g_gemm_dma_waves = (int)value;
+        c->tune.gemm_dma_waves = (int)value;
     } else if (!strcmp(name, "gemm_dma")) {
-        g_gemm_use_dma = value ? 1 : 0;
+        c->tune.gemm_use_dma = value ? 1 : 0;
     } else {
         return fail_arg("gpmi_set_option: unknown option");
     }
@@ -180,8 +188,9 @@ static int cov_impl(gpmi_ctx* c, int kind, const double* a, int64_t N, const dou
         return fail_arg("gpmi_cov: the periodic kernel is 1-D with non-zero period and lengthscale");
     if (N == 0 || M == 0) return GPMI_OK;
     HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
     hipStream_t s = c->stream;
-    DevBuf da, db, dout;
+    DevBuf &da = c->cov_a, &db = c->cov_b, &dout = c->cov_out;   // pooled: grow-only, freed with the context
     const int64_t Mp = round_up(M, TILE), ld = Mp + 32;
     const int64_t chunk = std::max<int64_t>(TILE, std::min<int64_t>(round_up(N, TILE),
                           ((int64_t)1 << 30) / (ld * 8) / TILE * TILE));
@@ -222,7 +231,6 @@ static int cov_impl(gpmi_ctx* c, int kind, const double* a, int64_t N, const dou
         }
     } while (0);
     (void)hipStreamSynchronize(s);
-    da.release(); db.release(); dout.release();
     return rc;
 }
 
@@ -246,6 +254,7 @@ int gpmi_factorize(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
                    int64_t* bad_pivot) {
     if (!c) return fail_arg("gpmi_factorize: null context");
     HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
     return factorize_impl(c, sigma, ell, noise_var, lml, bad_pivot);
 }
 
@@ -295,6 +304,7 @@ int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
     if (!c || !alpha_out) return fail_arg("gpmi_get_alpha: null argument");
     if (!c->have_factor) return fail_arg("gpmi_get_alpha: no factorisation resident");
     HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
     hipStream_t s = c->stream;
     c->timers_reset({GPMI_T_ALPHA});
     HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
@@ -333,6 +343,7 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     if (!c->have_factor) return fail_arg("gpmi_predict: no factorisation resident (call gpmi_factorize)");
     if (!c->have_test) return fail_arg("gpmi_predict: no test set (call gpmi_set_test)");
     HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
     hipStream_t s = c->stream;
     c->timers_reset({GPMI_T_KS, GPMI_T_SOLVE_V, GPMI_T_MEANVAR});
     c->have_v = false;
@@ -407,6 +418,7 @@ int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
     if (!c->have_factor) return fail_arg("gpmi_lml_grad: no factorisation resident (call gpmi_factorize)");
     if (c->kind != 0) return fail_arg("gpmi_lml_grad: squared-exponential kernel only (tune_hyperparms_regression.py:54)");
     HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
     hipStream_t s = c->stream;
     const int64_t Np = c->Np, ld = c->ldA;
     c->timers_reset({GPMI_T_GRAD});
@@ -519,6 +531,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     if (!c || !L_out) return fail_arg("gpmi_post_chol: null argument");
     if (!c->have_v) return fail_arg("gpmi_post_chol: run gpmi_predict first");
     HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
     hipStream_t s = c->stream;
     c->timers_reset({GPMI_T_POSTCHOL});
     const int64_t np_ = c->np_, n = c->n;
@@ -566,6 +579,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
 // N = 32768 213 -> 201 ms).
 static int lane_prepare(gpmi_ctx* c, gpmi_ctx* l) {
     l->nb = c->nb; l->ld_pad = c->ld_pad; l->lookahead = c->lookahead; l->ramp = c->ramp; l->timing = c->timing;
+    l->tune = c->tune;
     l->kind = c->kind; l->kp0 = c->kp0; l->kp1 = c->kp1;
     for (int i = 0; i < 11; ++i) l->kpv[i] = c->kpv[i];
     l->N = c->N; l->d = c->d; l->boxX = c->boxX;
@@ -609,6 +623,7 @@ int gpmi_lml_batch(gpmi_ctx* c, const double* triples, int64_t T, double* lml_ou
     std::vector<std::vector<double>> lane_ms((size_t)L, std::vector<double>(GPMI_T_COUNT, 0.0));
     auto work = [&](int r) {
         gpmi_ctx* l = lane[(size_t)r];
+        TuneScope tune_scope(&l->tune);         // this lane's thread runs with this lane's options
         if (hipSetDevice(l->device) != hipSuccess) { lane_rc[(size_t)r] = GPMI_ERR_RUNTIME; lane_err[(size_t)r] = "hipSetDevice"; return; }
         for (int64_t t = r; t < T; t += L) {
             const double ell = triples[3 * t], sigma = triples[3 * t + 1], s2 = triples[3 * t + 2];
@@ -650,5 +665,4 @@ int gpmi_get_timers(gpmi_ctx* c, double* stage_ms, int count) {
     return GPMI_OK;
 }
 
-// out[0] = TFLOP/s, out[1] = shader clock (GHz) held during the loop,
 }  // extern "C"

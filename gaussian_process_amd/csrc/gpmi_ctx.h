@@ -102,6 +102,7 @@ struct gpmi_ctx {
     int lanes = 0;          // gpmi_lml_batch: factorisations in flight (0 = by size)
     std::vector<gpmi_ctx*> lane_ctx;   // the extra lanes (own streams and workspaces), created on demand
     int ramp = 0;           // block widths ramp up at the start and down at the end of the sweep (measured: 0.4 % slower at N = 65536, off)
+    gpmi::Tuning tune;      // kernel-selection options of this context (installed per call: gpmi::TuneScope)
     // training set / factor
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
     bool have_train = false, have_factor = false;
@@ -116,6 +117,7 @@ struct gpmi_ctx {
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;
+    DevBuf cov_a, cov_b, cov_out;   // gpmi_rbf / gpmi_cov staging, kept across calls (the BO loops call them hundreds of times)
     DevBuf U, Kn, gpart;     // f2: L^-T, -(K+sI)^-1, per-tile partial sums of the gradient trace
     double sigma = 1.0, ell = 1.0;   // hyper-parameters of the resident factorisation
     // timers
@@ -124,28 +126,35 @@ struct gpmi_ctx {
     std::vector<TimedSpan> spans;
     double stage_ms[GPMI_T_COUNT] = {0};
 
+    // nullptr (and ev_error set) if the runtime cannot create another event
+    hipError_t ev_error = hipSuccess;
     hipEvent_t new_event() {
         if (ev_used == ev_pool.size()) {
-            hipEvent_t e;
-            (void)hipEventCreate(&e);
+            hipEvent_t e = nullptr;
+            const hipError_t r = hipEventCreateWithFlags(&e, hipEventDefault);
+            if (r != hipSuccess) { ev_error = r; return nullptr; }
             ev_pool.push_back(e);
         }
         return ev_pool[ev_used++];
     }
+    static constexpr size_t NO_SPAN = (size_t)-1;
+    // a span that cannot get its events is dropped (timers are diagnostics); ordering events are not optional
     size_t span_begin(int slot, hipStream_t st = nullptr) {
-        if (!timing) return 0;
+        if (!timing) return NO_SPAN;
         TimedSpan s{new_event(), new_event(), slot};
-        (void)hipEventRecord(s.a, st ? st : stream);
+        if (!s.a || !s.b) return NO_SPAN;
+        if (hipEventRecord(s.a, st ? st : stream) != hipSuccess) return NO_SPAN;
         spans.push_back(s);
         return spans.size() - 1;
     }
     void span_end(size_t idx, hipStream_t st = nullptr) {
-        if (!timing) return;
-        (void)hipEventRecord(spans[idx].b, st ? st : stream);
+        if (!timing || idx == NO_SPAN) return;
+        if (hipEventRecord(spans[idx].b, st ? st : stream) != hipSuccess) spans[idx].slot = GPMI_T_COUNT - 1;
     }
     // make stream `waiter` wait for everything queued so far on `signaller`
     hipError_t order(hipStream_t signaller, hipStream_t waiter) {
         hipEvent_t e = new_event();
+        if (!e) return ev_error;
         hipError_t r = hipEventRecord(e, signaller);
         if (r != hipSuccess) return r;
         return hipStreamWaitEvent(waiter, e, 0);

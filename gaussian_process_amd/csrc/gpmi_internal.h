@@ -4,10 +4,50 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 namespace gpmi {
 
 constexpr int TILE = 128;   // row / column padding granule of every matrix
 constexpr int IB = 64;      // inner (register-resident) panel width
+
+// Kernel-selection options (gpmi_set_option).  They live in the context; a C-ABI call installs its
+// context's set for the calling thread (TuneScope), so two contexts driven from two threads (the lanes
+// of gpmi_lml_batch) never see each other's settings.  The context-free gpmi_dev_* primitives run with
+// the defaults.
+struct Tuning {
+    int gemm_use_dma = 1;       // LDS-DMA GEMM for launches with >= 256 tiles
+    int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
+    int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
+    int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always
+    int rbf_blocks = 16384;     // persistent blocks of the register-path K build
+    int panel_fused = 1;        // 1: fused multi-column panel kernels, 0: first-generation potf2 + substitution leaves
+    int gemm_dbg = 0;           // timing-only ablation bits (gpmi_probe_gemm); results are wrong when non-zero
+    unsigned long long* gemm_stamps = nullptr;   // diagnostic stamp buffer (gpmi_probe_gemm variant bit 16)
+};
+const Tuning& tuning();         // options of the C-ABI call running on this thread
+struct TuneScope {
+    const Tuning* prev;
+    explicit TuneScope(const Tuning* t);
+    ~TuneScope();
+};
+
+// One-time, per-device opt-in (hipFuncSetAttribute for > 64 KiB of dynamic LDS): thread-safe, keyed by
+// the current device, and the error is returned instead of dropped.
+struct PerDeviceOnce {
+    std::mutex mu;
+    uint64_t done = 0;
+    template <class F> hipError_t run(F fn) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev < 64 && ((done >> dev) & 1)) return hipSuccess;
+        e = fn();
+        if (e == hipSuccess && dev < 64) done |= (uint64_t)1 << dev;
+        return e;
+    }
+};
 
 // ---- gemm_nt.hip ----------------------------------------------------------
 // C (M x N) op= A (M x K) * B (N x K)^T, all row-major.  M multiple of 128,
@@ -39,11 +79,6 @@ double gemm_nt_algorithmic_flops(const GemmArgs& a, int64_t real_rows);   // 2K 
 // gemm_dma.hip: one-workgroup-per-CU LDS-DMA variant (mode 0, N % 128 == 0)
 bool gemm_dma_eligible(const GemmArgs& a);
 hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
-extern unsigned long long* g_gemm_stamps;   // diagnostic stamp buffer (4096*4*4 u64) for gpmi_probe_gemm variant bit 16
-extern int g_gemm_dma_waves;  // 4 or 8 waves per workgroup in the LDS-DMA GEMM
-extern int g_gemm_small_tiles;   // 64 x 64 tiles for launches with few tiles
-extern int g_gemm_use_dma;   // 0: never, 1: for launches with >= 256 tiles
-extern int g_gemm_dbg;       // timing-only ablation bits for gpmi_probe_gemm (0 in production)
 // number of tiles the launch actually computes (for flop accounting)
 double gemm_nt_flops(const GemmArgs& a);
 
@@ -51,7 +86,6 @@ double gemm_nt_flops(const GemmArgs& a);
 // Cholesky of one 64x64 diagonal block in place (lower), one wavefront.
 hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_offset,
                            int64_t* info_dev);
-extern int g_trsm_wave;   // tuning switch: wave-per-row (1) or lane-per-row (0) substitution kernel
 // X (m x 64) <- X * L^-T, L 64x64 lower; m multiple of 64.
 hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
                              int64_t m);
@@ -83,7 +117,6 @@ struct RbfArgs {
     double max_sq = -1.0;
 };
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a);
-extern int g_rbf_blocks;      // persistent blocks of the register-path K build (option "rbf_blocks")
 
 // ---- grad.hip --------------------------------------------------------------
 // sum_ij (alpha_i alpha_j - K_y^-1_ij) dK_ij/dtheta over a block of rows (tune_hyperparms_regression.py:54-57)

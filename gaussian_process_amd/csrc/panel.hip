@@ -146,8 +146,6 @@ hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_off
 // One lane per row of X; L^T sits in LDS (column c of L contiguous) and is
 // read as wave-wide 16-byte broadcasts.  One true division per column per block.
 // ---------------------------------------------------------------------------
-int g_trsm_wave = 1;   // 1: wave-per-row kernel, 0: lane-per-row kernel
-
 constexpr int TRSM_THREADS = 128;
 
 template <int C>
@@ -252,7 +250,7 @@ hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double
     // short panels (diagonal blocks, small problems, a rank's share): the wave-per-row kernel,
     // whose latency is ~10x lower; tall panels run hidden under the trailing update, where the
     // lane-per-row kernel disturbs the concurrent MFMA stream less
-    if (g_trsm_wave && m <= 16384) {
+    if (tuning().trsm_wave && m <= 16384) {
         const int rows_per_block = (TRSM_WT / 64) * TRSM_WR;
         const int blocks = (int)((m + rows_per_block - 1) / rows_per_block);
         hipLaunchKernelGGL(trsm_rlt64_wave_kernel, dim3(blocks), dim3(TRSM_WT), 0, s, L, ldl, X, ldx, m);

@@ -57,6 +57,8 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
     if (M <= 0 || N <= 0 || K <= 0 || M % TILE || N % IB || K % 16 || reps < 1)
         return fail_arg("gpmi_probe_gemm: M%128, N%64, K%16 must be 0");
     HIP_TRY(hipSetDevice(c->device));
+    Tuning tn = c->tune;                 // this call's private copy carries the ablation bits
+    TuneScope tune_scope(&tn);
     hipStream_t s = c->stream;
     const int64_t ldc = N + c->ld_pad, ldk = K + c->ld_pad;
     DevBuf C, A, B;
@@ -76,16 +78,16 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
         if (variant & 16) {
             if ((e = stamps.ensure(4096 * 16 * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
             (void)hipMemsetAsync(stamps.p, 0, 4096 * 16 * 8, s);
-            g_gemm_stamps = stamps.as<unsigned long long>();
+            tn.gemm_stamps = stamps.as<unsigned long long>();
         }
-        g_gemm_dbg = variant;
+        tn.gemm_dbg = variant;
         e = launch_gemm_nt(s, g);
         (void)hipEventCreate(&ea); (void)hipEventCreate(&eb);
         (void)hipEventRecord(ea, s);
         for (int r = 0; r < reps && e == hipSuccess; ++r) e = launch_gemm_nt(s, g);
         (void)hipEventRecord(eb, s);
         hipError_t e2 = hipEventSynchronize(eb);
-        g_gemm_dbg = 0;
+        tn.gemm_dbg = 0;
         if (e != hipSuccess) { rc = fail_runtime(e, "gemm launch"); break; }
         if (e2 != hipSuccess) { rc = fail_runtime(e2, "gemm sync"); break; }
         float ms = 0.f;
@@ -101,11 +103,11 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
                 if (h[i + 1]) { for (int q = 0; q < 4; ++q) sum[q] += (double)h[i + q]; ++cnt; }
             if (cnt) fprintf(stderr, "[gemm stamps] waves %d: prologue %.0f  loop %.0f  epilogue-loads %.0f  epilogue-stores %.0f cycles\n",
                              cnt, sum[0] / cnt, sum[1] / cnt, sum[2] / cnt, sum[3] / cnt);
-            g_gemm_stamps = nullptr;
+            tn.gemm_stamps = nullptr;
             stamps.release();
         }
     } while (0);
-    g_gemm_dbg = 0;
+    tn.gemm_dbg = 0;
     if (ea) (void)hipEventDestroy(ea);
     if (eb) (void)hipEventDestroy(eb);
     (void)hipStreamSynchronize(s);

@@ -437,8 +437,6 @@ __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
     }
 }
 
-int g_rbf_blocks = 16384;   // persistent blocks of the register-path build
-
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     if (a.nrows <= 0 || a.ncols <= 0) return hipSuccess;
     if (a.nrows % RT || a.ncols % RT || a.d <= 0) return hipErrorInvalidValue;
@@ -465,7 +463,7 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     // big builds: 4 row tiles per block (b columns loaded once, 4x fewer block launches)
     p.strip = (nblk >= 4096) ? 4 : 1;
     p.nitems = p.Tn * ((p.Tm + p.strip - 1) / p.strip);
-    const dim3 sgrid((unsigned)std::min<int64_t>(p.nitems, g_rbf_blocks));
+    const dim3 sgrid((unsigned)std::min<int64_t>(p.nitems, tuning().rbf_blocks));
 #define RBF_CASE(DD) case DD: hipLaunchKernelGGL(rbf_regs_kernel<DD>, sgrid, block, 0, s, p.A, p.B, p.out, p); break
     if (a.d > LDS_MAXD) {
         hipLaunchKernelGGL(rbf_naive_kernel, grid, block, 0, s, p);

@@ -661,6 +661,8 @@ class DistGP:
         L never moves.  Returns the full alpha (N,) on every rank."""
         if not self.have_factor:
             raise ValueError("no factorisation resident (call factorize)")
+        import time
+        t_begin = time.perf_counter()
         ops, NB, G, A, T = self.ops, self.NB, self.G, self.A, self.T
         aloc = self._tensor(max(self.nloc, 1) * NB)
         aloc.zero_()
@@ -702,6 +704,7 @@ class DistGP:
         out = np.empty(self.Np)
         for b in range(T):
             out[b * NB:(b + 1) * NB] = R[b % G, b // G]
+        self.stage_ms["alpha"] = (time.perf_counter() - t_begin) * 1e3
         return out[:self.N].copy()
 
     def fit(self, X, y, sigma, ell, noise_var):

@@ -348,24 +348,39 @@ def co2_make_prediction(X_train, X_test, y_train, hyperparms):
 # baseline at sizes where the (N,d,N) broadcast does not fit, and as the
 # checker at mid sizes (N of a few thousand) where LU would take minutes.
 # ---------------------------------------------------------------------------
-def fit_predict_feasible(X_train, X_test, y_train, sigma, l, s, rows=256, use_c=True):
+def fit_predict_feasible(X_train, X_test, y_train, sigma, l, s, rows=256, use_c=True, timings=None):
+    """timings: optional dict that receives the wall seconds of each stage (bench.py's cpu_baseline:
+    kbuild, chol, trsv (both vector solves), ks, trsm, meanvar)."""
+    import time
     import scipy.linalg as sla
     N = len(X_train)
     if use_c:
         rbf = lambda a, b, sg, ll, rows=None: RBF_kernel_c(a, b, sg, ll)  # noqa: E731
     else:
         rbf = RBF_kernel_chunked
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + (t[-1] - t[-2])
     K = rbf(X_train, X_train, sigma, l, rows)
     K[np.diag_indices(N)] += s
+    lap("kbuild")
     L = sla.cholesky(K, lower=True, overwrite_a=True, check_finite=False)
+    lap("chol")
     m = sla.solve_triangular(L, y_train, lower=True, check_finite=False)
     alpha = sla.solve_triangular(L, m, lower=True, trans='T', check_finite=False)
+    lap("trsv")
     K_s = rbf(X_train, X_test, sigma, l, rows)
     mu = K_s.T @ alpha
+    lap("ks")
     v = sla.solve_triangular(L, K_s, lower=True, overwrite_b=True, check_finite=False)
+    lap("trsm")
     var = sigma ** 2 - np.einsum('ij,ij->j', v, v)
     lml = (-.5 * float(y_train @ alpha) - float(np.log(np.diagonal(L)).sum())
            - N / 2.0 * np.log(2 * np.pi))
+    lap("meanvar")
     return dict(mu=mu, var=var, alpha=alpha, m=m, lml=lml, diagL=np.diagonal(L).copy())
 
 

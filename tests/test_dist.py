@@ -96,7 +96,8 @@ def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
                                                 (2, 6144, 8, 128, 256, 1),    # large enough for the LDS-DMA GEMM + row map
                                                 (1, 1300, 8, 100, 256, 2), (2, 1500, 8, 200, 256, 2),
                                                 (3, 2100, 8, 130, 128, 2), (2, 6144, 8, 128, 256, 2),
-                                                (2, 6144, 8, 128, 2048, 2), (3, 6144, 8, 128, 1024, 2)])   # the bench's block rows
+                                                (2, 6144, 8, 128, 2048, 2), (3, 6144, 8, 128, 1024, 2),   # the bench's block rows
+                                                (2, 2304, 16, 150, 256, 2), (3, 2304, 16, 150, 128, 1)])    # cfg4's d
 def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
     res = _run(world, "gloo", "cuda", tmp_path, N, d, n, nb, lookahead=la)
     _check(res, oracle, N, d, n)
@@ -148,3 +149,47 @@ def test_row_map_update_live_supertiles_only(M, N, K, band_rows):
         outs.append(Cd.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     assert np.allclose(outs[1], want, rtol=0, atol=1e-10 * np.abs(want).max())
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    return p
+
+
+def test_bench_spawns_its_own_ranks_cpu():
+    """`python bench.py --gpus N` outside torch.distributed.run starts N fresh rank processes itself (the driver's
+    invocation).  GPMI_BENCH_SPAWN_ECHO makes every rank report its environment and exit before it imports torch."""
+    import json
+    p = _bench(["--gpus", "3"], {"GPMI_BENCH_SPAWN_ECHO": "1"}, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    seen = sorted((json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")), key=lambda r: r["rank"])
+    assert [r["rank"] for r in seen] == [0, 1, 2] and all(r["world"] == 3 and r["local_rank"] == r["rank"] for r in seen)
+    assert len({r["port"] for r in seen}) == 1 and all(r["addr"] == "127.0.0.1" for r in seen)
+    # a failing rank makes the parent exit non-zero
+    p = _bench(["--gpus", "2"], {"GPMI_BENCH_SPAWN_ECHO": "fail1"}, timeout=120)
+    assert p.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_through_the_self_spawn_path():
+    """The driver's multi-GPU command line, rehearsed on the one GPU of the test box: gloo moves the panels, both
+    ranks share device 0.  One JSON line from rank 0 with n_gpus = rccl_ranks = 2."""
+    import json
+    p = _bench(["--gpus", "2", "--size", "8192", "--ntest", "512", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+               {"GPMI_BENCH_BACKEND": "gloo", "GPMI_BENCH_ONE_DEVICE": "1"})
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["partition"] == "row-block cyclic x2"
+    assert out["value"] > 0 and np.isfinite(out["lml"]) and len(out["per_rank_ms"]) == 2
+    # the same problem on the single-GPU path: same log-marginal-likelihood to 1e-12 relative
+    p1 = _bench(["--gpus", "1", "--size", "8192", "--ntest", "512", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {})
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
+    assert abs(one["lml"] - out["lml"]) <= 1e-12 * abs(one["lml"])
+    assert "roofline" in one and "targets" in one

@@ -381,6 +381,43 @@ def test_cfg3_N65536_d8_properties(ctx, oracle):
     assert t["solve_v"] > 0 and t["ks"] > 0
 
 
+def test_cfg4_N131072_d16_single_gpu_properties(oracle):
+    """BASELINE config 4's workload (N=131072, d=16, l=2.8) on ONE GPU: K + L in place take 138 GB of the
+    288 GB.  No CPU oracle can run it, so it is checked through the size-independent properties (sampled rows of
+    (K + sI) alpha = y, y^T alpha = m^T m, K_i alpha = y_i - s alpha_i through predict, variances in [0, sigma^2],
+    mean vs K_s^T alpha).  Own context, closed afterwards, so that the 138 GB do not stay allocated for
+    the rest of the session.  The 8-rank partition of the same workload is tests/test_dist.py's schedule."""
+    from gaussian_process_amd import GPContext
+    X, y, Xs = oracle.synthetic_problem(131072, 16, 1024)
+    with GPContext(0) as big:
+        lml = _check_solution_properties(big, X, y, Xs, 1.0, 2.8, 5e-4)
+        t = big.timers()
+    assert np.isfinite(lml) and t["solve_v"] > 0
+
+
+def test_cfg5_64_triples_N32768(ctx, oracle):
+    """BASELINE config 5 at its own size on one GPU: 64 (l, sigma_f, sigma_n^2) triples (the 4 x 4 x 4 grid of
+    SURVEY.md section 8d) at N=32768, d=8 through gpmi_lml_batch -- the reference's loops at
+    tune_hyperparms_regression.py:368-369, 385-386 as one call.  Every triple with the reference's hard-coded
+    sigma_n^2 = 5e-4 must equal the single compute_mar_likelihood call bit for bit; two triples are checked
+    against the CPU oracle (LAPACK Cholesky at N=32768) to 1e-10 relative; all statuses 0."""
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    N = 32768
+    X, y, _ = oracle.synthetic_problem(N, 8, 4)
+    triples = np.array([[l, sf, s2] for l in (1., 2., 3., 4.) for sf in (.5, 1., 1.5, 2.) for s2 in (1e-4, 5e-4, 1e-3, 5e-3)])
+    assert triples.shape == (64, 3)
+    ctx.set_train(X, y)
+    lml, status = ctx.lml_batch(triples)
+    assert np.all(status == 0) and np.all(np.isfinite(lml))
+    for t, (l, sf, s2) in enumerate(triples):
+        if s2 == 5e-4:
+            assert T.compute_mar_likelihood(X, None, y, sf, l, ctx=ctx) == lml[t], (t, l, sf)
+    for t in (5, 41):                       # (1, 1, 5e-4) and (3, 1.5, 5e-4)
+        l, sf, s2 = triples[t]
+        ref = oracle.fit_predict_feasible(X, X[:1], y, sf, l, s2)["lml"]
+        assert abs(lml[t] - ref) <= LML_RTOL * abs(ref), (t, lml[t], ref)
+
+
 def test_d16_N8192_properties(ctx, oracle):
     X, y, Xs = oracle.synthetic_problem(8192, 16, 300)
     _check_solution_properties(ctx, X, y, Xs, 1.0, 2.8, 5e-4)
