@@ -61,6 +61,7 @@ SIGNATURES = {
     "gpmi_probe_gemm": [_vp, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _dp],
     "gpmi_probe_hbm_write": [_vp, _i64, _dp],
     "gpmi_probe_hbm_ex": [_vp, _i64, C.c_int, C.c_int, _dp],
+    "gpmi_probe_panel": [_vp, C.c_int, _i64, C.c_int, _dp, C.POINTER(C.c_uint64)],
     "gpmi_dev_rbf_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, C.c_double, _vp, _i64],
     "gpmi_dev_rbf_cross": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _vp, _i64],
     "gpmi_dev_potrf_block": [_vp, _vp, _i64, _i64, _i64, _vp],
@@ -86,6 +87,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch (this framework's plumbing for device memory, streams and torch.distributed) ships its own copy of
+    # the HIP runtime; whichever copy a process loads first is the one that owns the GPU.  Load torch's first when
+    # torch is importable, so the library and torch share one runtime (the other order leaves torch with
+    # "No HIP GPUs are available").
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise GpmiLibraryMissing(
             "libgpmi355x.so not found at %s -- build it with "

@@ -20,14 +20,23 @@ namespace gpmi {
 hipError_t panel_rec(hipStream_t s, double* A, int64_t ld, int64_t mrows, int64_t off, int64_t w,
                      int64_t col_offset, int64_t* info) {
     hipError_t e;
-    if (w <= IB) {
+    // leaves: 128 columns on the matrix pipe (potrf128 + trsm128, panel_mfma.hip), or -- option
+    // "panel_fused" 0, and widths that are not a multiple of 128 -- the first-generation 64-column pair
+    const bool fused = tuning().panel_fused && w % 128 == 0 && off % 128 == 0;
+    const int64_t leaf = fused ? 128 : IB;
+    if (w <= leaf) {
         double* Ajj = A + off * ld + off;
+        const int64_t below = mrows - off - leaf;
+        if (fused) {
+            if ((e = launch_potrf128(s, Ajj, ld, col_offset + off, info)) != hipSuccess) return e;
+            if (below > 0) return launch_trsm128(s, Ajj, ld, A + (off + leaf) * ld + off, ld, below);
+            return hipSuccess;
+        }
         if ((e = launch_potf2_64(s, Ajj, ld, col_offset + off, info)) != hipSuccess) return e;
-        const int64_t below = mrows - off - IB;
         if (below > 0) return launch_trsm_rlt64(s, Ajj, ld, A + (off + IB) * ld + off, ld, below);
         return hipSuccess;
     }
-    const int64_t h = (w / 2) / IB * IB;           // left width (multiple of 64, >= 64)
+    const int64_t h = (w / 2) / leaf * leaf;       // left width (multiple of the leaf width, >= one leaf)
     if ((e = panel_rec(s, A, ld, mrows, off, h, col_offset, info)) != hipSuccess) return e;
     {
         // right half -= (rows of the left half) * (its own rows of the left half)^T, lower part.
@@ -57,8 +66,13 @@ hipError_t panel_factor(hipStream_t s, double* A, int64_t ld, int64_t nb, int64_
 hipError_t trsm_rec(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m,
                     int64_t off, int64_t w) {
     hipError_t e;
-    if (w <= IB) return launch_trsm_rlt64(s, L + off * ldl + off, ldl, X + off, ldx, m);
-    const int64_t h = (w / 2) / IB * IB;
+    const bool fused = tuning().panel_fused && w % 128 == 0 && off % 128 == 0 && m % 128 == 0;
+    const int64_t leaf = fused ? 128 : IB;
+    if (w <= leaf) {
+        if (fused) return launch_trsm128(s, L + off * ldl + off, ldl, X + off, ldx, m);
+        return launch_trsm_rlt64(s, L + off * ldl + off, ldl, X + off, ldx, m);
+    }
+    const int64_t h = (w / 2) / leaf * leaf;
     if ((e = trsm_rec(s, L, ldl, X, ldx, m, off, h)) != hipSuccess) return e;
     GemmArgs g;
     g.C = X + off + h;
@@ -247,6 +261,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     // tune_hyperparms_regression.py:312, with y^T alpha = m^T m
     if (lml) *lml = -.5 * red[1] - red[0] - (double)c->N / 2.0 * std::log(2 * M_PI);
     c->have_factor = true;
+    c->factor_fused = tuning().panel_fused;
     return GPMI_OK;
 }
 

@@ -343,7 +343,9 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     if (!c->have_factor) return fail_arg("gpmi_predict: no factorisation resident (call gpmi_factorize)");
     if (!c->have_test) return fail_arg("gpmi_predict: no test set (call gpmi_set_test)");
     HIP_TRY(hipSetDevice(c->device));
-    TuneScope tune_scope(&c->tune);
+    Tuning tn = c->tune;
+    tn.panel_fused = c->factor_fused;      // solve with the kind of leaves that produced the resident factor
+    TuneScope tune_scope(&tn);
     hipStream_t s = c->stream;
     c->timers_reset({GPMI_T_KS, GPMI_T_SOLVE_V, GPMI_T_MEANVAR});
     c->have_v = false;
@@ -418,7 +420,9 @@ int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
     if (!c->have_factor) return fail_arg("gpmi_lml_grad: no factorisation resident (call gpmi_factorize)");
     if (c->kind != 0) return fail_arg("gpmi_lml_grad: squared-exponential kernel only (tune_hyperparms_regression.py:54)");
     HIP_TRY(hipSetDevice(c->device));
-    TuneScope tune_scope(&c->tune);
+    Tuning tn = c->tune;
+    tn.panel_fused = c->factor_fused;
+    TuneScope tune_scope(&tn);
     hipStream_t s = c->stream;
     const int64_t Np = c->Np, ld = c->ldA;
     c->timers_reset({GPMI_T_GRAD});

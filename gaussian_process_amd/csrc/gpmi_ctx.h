@@ -106,6 +106,8 @@ struct gpmi_ctx {
     // training set / factor
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
     bool have_train = false, have_factor = false;
+    int factor_fused = 1;    // the resident factor came from the fused panel kernels: its diagonal 16 x 16 tiles carry
+                             // their inverses above the diagonal, which trsm128 reads (panel_mfma.hip)
     double sig2 = 1.0, coef = -0.5;
     int kind = 0;            // covariance function: 0 rbf, 1 linear, 2 periodic, 3 CO2 composite (gpmi_set_kernel*)
     double kp0 = 0., kp1 = 0.;

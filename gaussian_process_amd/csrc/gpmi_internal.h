@@ -24,6 +24,7 @@ struct Tuning {
     int panel_fused = 1;        // 1: fused multi-column panel kernels, 0: first-generation potf2 + substitution leaves
     int gemm_dbg = 0;           // timing-only ablation bits (gpmi_probe_gemm); results are wrong when non-zero
     unsigned long long* gemm_stamps = nullptr;   // diagnostic stamp buffer (gpmi_probe_gemm variant bit 16)
+    unsigned long long* panel_stamps = nullptr;  // diagnostic: s_memtime stamps of the panel kernels (gpmi_probe_panel)
 };
 const Tuning& tuning();         // options of the C-ABI call running on this thread
 struct TuneScope {
@@ -89,6 +90,12 @@ hipError_t launch_potf2_64(hipStream_t s, double* A, int64_t ld, int64_t col_off
 // X (m x 64) <- X * L^-T, L 64x64 lower; m multiple of 64.
 hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx,
                              int64_t m);
+
+// ---- panel_mfma.hip --------------------------------------------------------
+// Cholesky of one 128 x 128 diagonal block in place (lower), one workgroup, MFMA updates.
+hipError_t launch_potrf128(hipStream_t s, double* A, int64_t ld, int64_t col_offset, int64_t* info_dev);
+// X (m x 128) <- X * L^-T, L 128 x 128 lower; m multiple of 128; on the matrix pipe.
+hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m);
 
 // ---- rbf.hip ---------------------------------------------------------------
 struct RbfArgs {

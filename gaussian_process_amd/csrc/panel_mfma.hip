@@ -1,0 +1,416 @@
+// Second-generation panel kernels: the latency chain of a block step on the matrix pipe.
+//
+//   potrf128_kernel   Cholesky of a 128 x 128 diagonal block by ONE workgroup (8 waves).
+//   trsm128_kernel    X (m x 128) <- X * L^-T for the rows below it, 16 rows per wave, chip-wide.
+//
+// They replace the chains potf2_64 -> trsm_rlt64 -> rank-64 GEMM (two of each per 128 columns, all
+// latency-bound launches; the substitution kernels were fp64 VALU) behind np.linalg.cholesky and the
+// LU-based np.linalg.solve of the reference (GP_regression.py:138-139, 144).
+//
+// Everything except the 16 x 16 diagonal blocks runs on v_mfma_f64_16x16x4_f64.  The 16 x 16 blocks are
+// factored AND inverted by one wave with the rows in registers (v_readlane broadcasts, no LDS, no barrier);
+// with W_jj = L_jj^-1 at hand, "rows below" is a matrix product  L_ij = S_ij * W_jj^T  and so is every update.
+// Only 16 x 16 inverses are ever formed (cond(L_jj) of a 16 x 16 diagonal block, never of the panel).
+//
+// Register layout of a 16 x 16 tile X (rows n, columns c) -- "X layout": lane (fr = lane & 15, fg = lane >> 4)
+// holds x[v] = X[fr][kap(fg, v)],  kap(g, v) = 2g + (v & 1) + 8 (v >> 1): two 16-byte pieces of row fr.
+// This IS the B-operand layout of the MFMA up to a permutation of the summation index (which both
+// operands share), and -- with the rows of the A operand permuted by rho(g + 4v) = kap(g, v) -- also the
+// layout the MFMA writes its result in.  So a tile that has just been produced feeds the next products
+// straight from its accumulator registers: no shuffles, no LDS round trip for X.
+//   Y[c][n] = sum_k M[c][k] X[n][k]:   acc = mfma(a_v, x[v], acc), v = 0..3,
+//   a_v(lane) = M[rho(lane & 15)][kap(lane >> 4, v)],   new x[v] = acc[v].
+// The A operands (W_jj, -L_kj) live in LDS as 16 rows x 128 bytes, row i' = M[rho(i')][:], 16-byte slots
+// XOR-swizzled by (i' >> 1) & 7: both ds_read_b128 of a fragment are conflict-free (brute-force checked).
+#include "gpmi_internal.h"
+
+namespace gpmi {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int PB = 128;                 // panel block width
+constexpr int NT = PB / 16;             // 16 x 16 tiles per side
+constexpr int TILE_BYTES = 16 * 128;
+constexpr int NTILES = NT * (NT + 1) / 2;
+constexpr int TRSM_ROWS = 64;            // rows per trsm128 workgroup pass (4 waves x 16)
+constexpr int SCR_LD = 18;              // doubles per scratch row (16-byte aligned rows, conflict-free row reads)
+
+__device__ __forceinline__ int kap(int g, int v) { return 2 * g + (v & 1) + 8 * (v >> 1); }
+// LDS row that holds matrix row n: rho^-1(n)
+__device__ __forceinline__ int rho_inv(int n) { return ((n >> 1) & 3) + 4 * (n & 1) + 8 * (n >> 3); }
+__device__ __forceinline__ int tile_index(int j, int k) { return j * (j + 1) / 2 + k; }   // k <= j
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rcp_newton(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-p, y, 1.0);
+    return fma(y, e, y);
+}
+
+// address (in d2 units) of slot s of row i' inside a tile
+__device__ __forceinline__ int tslot(int row, int s) { return row * 8 + (s ^ ((row >> 1) & 7)); }
+
+// A-operand fragments of a tile for this lane: a[v] = M[rho(lane & 15)][kap(lane >> 4, v)]
+__device__ __forceinline__ void load_afrag(const d2* tile, int lane, double (&a)[4]) {
+    const int i = lane & 15, kk = lane >> 4;
+    const d2 lo = tile[tslot(i, kk)], hi = tile[tslot(i, 4 + kk)];
+    a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
+}
+
+// publish a tile held in X layout (element (fr, kap(fg, v))) as an A operand, scaled by sgn
+__device__ __forceinline__ void publish_tile(d2* tile, int lane, const double (&x)[4], double sgn) {
+    const int row = rho_inv(lane & 15), fg = lane >> 4;
+    tile[tslot(row, fg)] = d2{sgn * x[0], sgn * x[1]};
+    tile[tslot(row, 4 + fg)] = d2{sgn * x[2], sgn * x[3]};
+}
+
+// y = M * X^T in X layout (see the file header); acc_in is the C operand
+__device__ __forceinline__ void tile_mma(const double (&a)[4], const double (&b)[4], double (&c)[4]) {
+    d4 acc = d4{c[0], c[1], c[2], c[3]};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[v], b[v], acc, 0, 0, 0);
+    c[0] = acc[0]; c[1] = acc[1]; c[2] = acc[2]; c[3] = acc[3];
+}
+
+__device__ __forceinline__ void load_xtile(const double* p, int64_t ld, int lane, double (&x)[4]) {
+    const double* r = p + (int64_t)(lane & 15) * ld + 2 * (lane >> 4);
+    const d2 lo = *reinterpret_cast<const d2*>(r), hi = *reinterpret_cast<const d2*>(r + 8);
+    x[0] = lo.x; x[1] = lo.y; x[2] = hi.x; x[3] = hi.y;
+}
+__device__ __forceinline__ void store_xtile(double* p, int64_t ld, int lane, const double (&x)[4]) {
+    double* r = p + (int64_t)(lane & 15) * ld + 2 * (lane >> 4);
+    *reinterpret_cast<d2*>(r) = d2{x[0], x[1]};
+    *reinterpret_cast<d2*>(r + 8) = d2{x[2], x[3]};
+}
+
+// ---------------------------------------------------------------------------
+// Cholesky AND inverse of a 16 x 16 block by one wave, rows in registers, no LDS, no barrier.
+// Lanes 0..15: lane r holds row r of the symmetric positive definite block in v[0..15] (entries k <= r are
+// read).  Lanes 16..31: lane 16 + c holds column c of the identity.  Right-looking sweep, column c:
+//     p = v[c] of lane c;  v[c] *= 1/sqrt(p);  v[k] -= L[k][c] * v[c]  for k > c,  L[k][c] = v[c] of lane k.
+// The same instructions run the forward substitution W = L^-1 on lanes 16..31 (both need the scalar L[k][c],
+// one v_readlane pair per (c, k)), so the inverse costs no instruction of its own.  The chain pivot ->
+// 1/sqrt -> scale -> next pivot is software-pipelined by hand: column c + 1's reciprocal square root runs
+// stage by stage between the updates of column c (the order below is pinned with scheduling barriers; left to
+// itself the compiler splits the loop in two and spills the scalars).
+// Afterwards: lane r holds L[r][k] in v[k] (k <= r); lane 16 + c holds W[r][c] in v[r] (zero for r < c).
+// Returns the first non-positive pivot (16 if none).
+// ---------------------------------------------------------------------------
+struct RsqChain {      // 1/sqrt(p) and sqrt(p) in stages (v_rsq_f64 + two coupled Newton steps + residual fix)
+    double p, y, g, h, r;
+    __device__ __forceinline__ void stage(int i) {
+        switch (i) {
+            case 0: y = __builtin_amdgcn_rsq(p); break;
+            case 1: g = p * y; h = 0.5 * y; break;
+            case 2: r = fma(-h, g, 0.5); break;
+            case 3: g = fma(g, r, g); h = fma(h, r, h); break;
+            case 4: r = fma(-h, g, 0.5); break;
+            case 5: g = fma(g, r, g); h = fma(h, r, h); break;
+            case 6: r = fma(-g, g, p); break;
+            case 7: g = fma(r, h, g); h = h + h; break;        // g = sqrt(p), h = 1/sqrt(p)
+            default: break;
+        }
+    }
+};
+constexpr int RSQ_STAGES = 8;
+#define PANEL_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ int factor16_packed(double (&v)[16], int lane) {
+    int bad = 16;
+    RsqChain ch;
+    ch.p = readlane_d(v[0], 0);
+#pragma unroll
+    for (int i = 0; i < RSQ_STAGES; ++i) ch.stage(i);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const bool ok = ch.p > 0.0;
+        if (!ok && bad == 16) bad = c;
+        const double s = ok ? ch.g : __builtin_nan("");
+        const double rinv = ok ? ch.h : __builtin_nan("");
+        v[c] = (lane == c) ? s : v[c] * rinv;
+        PANEL_FENCE();
+        int st = 0;
+        if (c < 15) {
+            const double l1 = readlane_d(v[c], c + 1);
+            v[c + 1] = fma(-l1, v[c], v[c + 1]);
+            PANEL_FENCE();
+            ch.p = readlane_d(v[c + 1], c + 1);          // next pivot: its chain overlaps the updates below
+            ch.stage(st++);
+            PANEL_FENCE();
+        }
+        // the scalars of the whole column first (a v_readlane result is not usable for ~10 cycles), then the
+        // updates, one chain stage of the next pivot between every two of them
+        double lk[16];
+#pragma unroll
+        for (int k = c + 2; k < 16; ++k) lk[k] = readlane_d(v[c], k);
+        PANEL_FENCE();
+#pragma unroll
+        for (int k = c + 2; k < 16; ++k) {
+            v[k] = fma(-lk[k], v[c], v[k]);
+            if (st < RSQ_STAGES && ((k - c) & 1)) { PANEL_FENCE(); ch.stage(st++); PANEL_FENCE(); }
+        }
+        PANEL_FENCE();
+        if (c < 15) {
+#pragma unroll
+            for (int i = 0; i < RSQ_STAGES; ++i)
+                if (i >= st) ch.stage(i);
+            PANEL_FENCE();
+        }
+    }
+    return bad;
+}
+
+// lane 16 + c holds column c of W (v[r] = W[r][c]): write it as an A-operand tile
+__device__ __forceinline__ void publish_w(double* tile, int lane, const double (&v)[16]) {
+    if (lane >= 16 && lane < 32) {
+        const int c = lane - 16;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rho_inv(r);
+            tile[2 * tslot(row, c >> 1) + (c & 1)] = v[r];
+        }
+    }
+}
+
+// Phase 1 of a potrf128 step, one copy of the code for all eight steps (everything it touches is behind
+// pointers): the diagonal tile sits row-major in `scratch`; factor + invert; to memory: L_jj on and below the
+// diagonal of the tile and W_jj TRANSPOSED strictly above it (tile[c][r] = W[r][c], r > c; the diagonal of W is
+// 1 / diag(L)) -- the strict upper triangles of the diagonal 16 x 16 tiles are storage nothing else reads, and
+// every later triangular solve with this block (trsm128, the backward solve) finds its inverse there instead
+// of recomputing it; W_jj as an A operand to its LDS tile; a non-positive pivot to *info.
+__device__ __noinline__ void factor_diag_tile(const double* scratch, double* Ajj, int64_t ld, double* wtile,
+                                              int64_t col0, int64_t* info) {
+    const int lane = threadIdx.x & 63;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const d2 t = *reinterpret_cast<const d2*>(scratch + (lane & 15) * SCR_LD + k);
+        v[k] = (lane < 16) ? t.x : ((lane - 16 == k) ? 1.0 : 0.0);
+        v[k + 1] = (lane < 16) ? t.y : ((lane - 16 == k + 1) ? 1.0 : 0.0);
+    }
+    const int bad = factor16_packed(v, lane);
+    if (bad < 16 && lane == 0) atomicMin((unsigned long long*)info, (unsigned long long)(col0 + bad));
+    if (lane < 32) {
+        double* row = Ajj + (int64_t)(lane & 15) * ld;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool mine = (lane < 16) ? (k <= lane) : (k > lane - 16);
+            if (mine) row[k] = v[k];
+        }
+    }
+    publish_w(wtile, lane, v);
+}
+
+// Staging of a diagonal tile in trsm128: W_jj as an A operand from the factored tile G at Ljj -- W[n][k] =
+// G[k][n] for k < n (stored transposed above the diagonal by factor_diag_tile), 1 / G[n][n] on the diagonal.
+__device__ __forceinline__ void stage_w_tile(const double* Ljj, int64_t ldl, d2* wtile, int lane) {
+    const int n = lane & 15, fg = lane >> 4;
+    double x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = kap(fg, q);
+        double val = 0.0;
+        if (k < n) val = Ljj[(int64_t)k * ldl + n];
+        else if (k == n) val = rcp_newton(Ljj[(int64_t)n * ldl + n]);
+        x[q] = val;
+    }
+    publish_tile(wtile, lane, x, 1.0);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// potrf128: A (128 x 128, lower, leading dimension ld) <- its Cholesky factor, one workgroup of 8 waves.
+// Wave i owns block row i (tiles (i, 0..i)) in registers for the whole kernel.  Step j:
+//   1  wave j       factors + inverts its diagonal tile, writes L_jj to memory and W_jj to LDS
+//   2  waves i > j  L_ij = S_ij W_jj^T (4 MFMAs), to memory and, negated, to LDS
+//   3  waves i > j  S_ik -= L_ij L_kj^T for k = j+1..i (4 MFMAs per tile), the diagonal chain first
+// Two barriers per step; a wave's tiles never leave its registers.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, int64_t col_offset, int64_t* info,
+                                                        unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    d2* tiles = reinterpret_cast<d2*>(smem);                                    // NTILES x 2 KiB
+    double* scratch = reinterpret_cast<double*>(smem + NTILES * TILE_BYTES);    // 16 x SCR_LD doubles
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+
+    double xt[NT][4];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        if (k <= wave) load_xtile(A + (int64_t)(16 * wave) * ld + 16 * k, ld, lane, xt[k]);
+        else { xt[k][0] = xt[k][1] = xt[k][2] = xt[k][3] = 0.0; }
+    }
+
+    // diagnostic (gpmi_probe_panel): stamps[6 j + q] = clock at the q-th boundary of step j, as seen by wave j
+    // (phase 1 begin / end) and wave min(j + 1, 7) (after barrier, after phase 2, after barrier, after phase 3)
+#define PANEL_STAMP(cond, idx) if (stamps && (cond) && lane == 0) stamps[idx] = __builtin_amdgcn_s_memtime()
+    PANEL_STAMP(wave == 0, 48);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        PANEL_STAMP(wave == j, 6 * j);
+        if (wave == j) {
+            // X layout -> one row per lane through the scratch tile
+#pragma unroll
+            for (int v = 0; v < 4; ++v) scratch[fr * SCR_LD + kap(fg, v)] = xt[j][v];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            factor_diag_tile(scratch, A + (int64_t)(16 * j) * ld + 16 * j, ld,
+                             reinterpret_cast<double*>(tiles + tile_index(j, j) * 128), col_offset + 16 * j, info);
+        }
+        PANEL_STAMP(wave == j, 6 * j + 1);
+        __syncthreads();
+        PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 2);
+        if (wave > j) {
+            double a[4], z[4] = {0., 0., 0., 0.};
+            load_afrag(tiles + tile_index(j, j) * 128, lane, a);
+            tile_mma(a, xt[j], z);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xt[j][v] = z[v];
+            publish_tile(tiles + tile_index(wave, j) * 128, lane, xt[j], -1.0);
+            store_xtile(A + (int64_t)(16 * wave) * ld + 16 * j, ld, lane, xt[j]);
+        }
+        PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 3);
+        __syncthreads();
+        PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 4);
+        if (wave > j) {
+#pragma unroll
+            for (int k = j + 1; k < NT; ++k) {
+                if (k <= wave) {
+                    double a[4];
+                    load_afrag(tiles + tile_index(k, j) * 128, lane, a);
+                    tile_mma(a, xt[j], xt[k]);
+                }
+            }
+        }
+        PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 5);
+    }
+    PANEL_STAMP(wave == 7, 49);
+}
+
+// ---------------------------------------------------------------------------
+// trsm128: X (m x 128) <- X * L^-T, L 128 x 128 lower (its upper triangle is not read).
+// Workgroup = 4 waves, two workgroups per CU; staging: the 28 off-diagonal tiles of L go to LDS negated, the 8
+// diagonal tiles contribute their stored inverses -- every workgroup does this for itself (72 KiB out of L2,
+// behind the load of its first rows), then walks slabs of 64 rows, 16 rows per wave, all 128 columns of a row
+// in 64 registers:
+//   for j = 0..7:  X_j <- X_j W_jj^T;   X_k -= X_j L_kj^T  for k > j         (144 MFMAs per 16 rows)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_t ldl, double* X, int64_t ldx,
+                                                          int64_t nslabs, unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    d2* tiles = reinterpret_cast<d2*>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#define PANEL_STAMP(cond, idx) if (stamps && (cond) && lane == 0) stamps[idx] = __builtin_amdgcn_s_memtime()
+    PANEL_STAMP(blockIdx.x == 0 && wave == 0, 56);
+
+    // the first slab's rows are requested before L is staged: their latency hides behind the staging
+    double xt[NT][4];
+    int64_t slab = blockIdx.x;
+    if (slab < nslabs) {
+        const double* Xr = X + (slab * TRSM_ROWS + 16 * wave) * ldx;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
+    }
+    // ---- stage L: wave w takes the off-diagonal tiles t = w, w + 4, ... and the diagonal tiles w, w + 4
+    {
+        int t = 0;
+#pragma unroll
+        for (int j = 1; j < NT; ++j)
+#pragma unroll
+            for (int k = 0; k < j; ++k, ++t) {
+                if ((t & 3) == wave) {
+                    double x[4];
+                    load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
+                    publish_tile(tiles + tile_index(j, k) * 128, lane, x, -1.0);
+                }
+            }
+        PANEL_STAMP(blockIdx.x == 0 && wave == 0, 57);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = wave + 4 * q;
+            stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + tile_index(j, j) * 128, lane);
+        }
+    }
+    PANEL_STAMP(blockIdx.x == 0 && wave == 0, 58);
+    __syncthreads();
+    PANEL_STAMP(blockIdx.x == 0 && wave == 0, 59);
+
+    for (; slab < nslabs; slab += gridDim.x) {
+        double* Xr = X + (slab * TRSM_ROWS + 16 * wave) * ldx;
+        if (slab != (int64_t)blockIdx.x) {
+#pragma unroll
+            for (int k = 0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
+        }
+        if (stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PANEL_STAMP(blockIdx.x == 0 && wave == 0 && slab == blockIdx.x, 60);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            double a[4], z[4] = {0., 0., 0., 0.};
+            load_afrag(tiles + tile_index(j, j) * 128, lane, a);
+            tile_mma(a, xt[j], z);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xt[j][v] = z[v];
+#pragma unroll
+            for (int k = j + 1; k < NT; ++k) {
+                double b[4];
+                load_afrag(tiles + tile_index(k, j) * 128, lane, b);
+                tile_mma(b, xt[j], xt[k]);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one step's operand fragments at a time (register pressure)
+        }
+        PANEL_STAMP(blockIdx.x == 0 && wave == 0 && slab == blockIdx.x, 61);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) store_xtile(Xr + 16 * k, ldx, lane, xt[k]);
+    }
+    PANEL_STAMP(blockIdx.x == 0 && wave == 0, 62);
+#undef PANEL_STAMP
+}
+
+static hipError_t panel_mfma_attrs() {
+    static PerDeviceOnce once;
+    return once.run([]() -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)potrf128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           NTILES * TILE_BYTES + 16 * SCR_LD * 8);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)trsm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   NTILES * TILE_BYTES);
+    });
+}
+
+hipError_t launch_potrf128(hipStream_t s, double* A, int64_t ld, int64_t col_offset, int64_t* info_dev) {
+    if (ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15)) return hipErrorInvalidValue;
+    hipError_t e = panel_mfma_attrs();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(512), NTILES * TILE_BYTES + 16 * SCR_LD * 8, s, A, ld, col_offset,
+                       info_dev, tuning().panel_stamps);
+    return hipGetLastError();
+}
+
+hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m) {
+    if (m <= 0) return hipSuccess;
+    if (m % TRSM_ROWS || ldl % 2 || ldx % 2 || (reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(X) & 15))
+        return hipErrorInvalidValue;
+    hipError_t e = panel_mfma_attrs();
+    if (e != hipSuccess) return e;
+    const int64_t nslabs = m / TRSM_ROWS;
+    const unsigned grid = (unsigned)std::min<int64_t>(nslabs, 512);     // two workgroups per CU (72 KiB of LDS each)
+    hipLaunchKernelGGL(trsm128_kernel, dim3(grid), dim3(256), NTILES * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
+                       tuning().panel_stamps);
+    return hipGetLastError();
+}
+
+}  // namespace gpmi

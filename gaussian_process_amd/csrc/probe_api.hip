@@ -141,6 +141,71 @@ int gpmi_probe_hbm_ex(gpmi_ctx* c, int64_t bytes, int mode, int blocks, double* 
     return GPMI_OK;
 }
 
+// Panel kernels alone on scratch data: kind 0 potrf128 (one 128 x 128 block), kind 1 trsm128 on m rows.
+// out_us = median-free mean microseconds per launch over reps; stamps_out (64 entries, may be null) = the
+// s_memtime stamps of one further, instrumented launch (layout: panel_mfma.hip).
+int gpmi_probe_panel(gpmi_ctx* c, int kind, int64_t m, int reps, double* out_us, uint64_t* stamps_out) {
+    if (!c || !out_us || reps < 1 || kind < 0 || kind > 1 || (kind == 1 && (m <= 0 || m % TILE)))
+        return fail_arg("gpmi_probe_panel: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    Tuning tn = c->tune;
+    TuneScope tune_scope(&tn);
+    hipStream_t s = c->stream;
+    const int64_t ld = 128 + 32, rows = 128 + (kind == 1 ? m : 0);
+    DevBuf A, st, info;
+    HIP_TRY(A.ensure((size_t)rows * ld * 8));
+    HIP_TRY(st.ensure(64 * 8));
+    HIP_TRY(info.ensure(8));
+    std::vector<double> h((size_t)rows * ld, 0.0);
+    for (int64_t i = 0; i < rows; ++i)
+        for (int64_t j = 0; j < 128; ++j)
+            h[(size_t)(i * ld + j)] = (i < 128) ? ((i == j) ? 2.0 : 0.5 / (1.0 + (double)(i > j ? i - j : j - i)))
+                                                : 0.001 * (double)((i * 7 + j * 13) % 97);
+    HIP_TRY(hipMemcpy(A.p, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(st.p, 0, 64 * 8));
+    double* Ad = A.as<double>();
+    DevBuf pristine;
+    HIP_TRY(pristine.ensure((size_t)128 * ld * 8));
+    HIP_TRY(hipMemcpy(pristine.p, A.p, (size_t)128 * ld * 8, hipMemcpyDeviceToDevice));
+    auto restore = [&]() -> hipError_t {     // potrf128 works in place: every launch gets the same SPD block
+        return kind == 0 ? hipMemcpyAsync(A.p, pristine.p, (size_t)128 * ld * 8, hipMemcpyDeviceToDevice, s) : hipSuccess;
+    };
+    auto once = [&]() -> hipError_t {
+        return kind == 0 ? launch_potrf128(s, Ad, ld, 0, info.as<int64_t>()) : launch_trsm128(s, Ad, ld, Ad + 128 * ld, ld, m);
+    };
+    if (kind == 1) HIP_TRY(launch_potrf128(s, Ad, ld, 0, info.as<int64_t>()));
+    HIP_TRY(restore());
+    HIP_TRY(once());
+    hipEvent_t ea, eb, ec;
+    HIP_TRY(hipEventCreate(&ea));
+    HIP_TRY(hipEventCreate(&eb));
+    HIP_TRY(hipEventCreate(&ec));
+    HIP_TRY(hipEventRecord(ea, s));
+    hipError_t e = hipSuccess;
+    for (int r = 0; r < reps && e == hipSuccess; ++r) { e = restore(); if (e == hipSuccess) e = once(); }
+    HIP_TRY(hipEventRecord(eb, s));
+    for (int r = 0; r < reps && e == hipSuccess; ++r) e = restore();
+    HIP_TRY(hipEventRecord(ec, s));
+    HIP_TRY(hipEventSynchronize(ec));
+    float ms = 0.f, ms_copy = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ea, eb));
+    HIP_TRY(hipEventElapsedTime(&ms_copy, eb, ec));
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb); (void)hipEventDestroy(ec);
+    if (e != hipSuccess) return fail_runtime(e, "panel kernel");
+    *out_us = (ms - ms_copy) * 1e3 / reps;
+    HIP_TRY(restore());
+    if (stamps_out) {
+        tn.panel_stamps = st.as<unsigned long long>();
+        HIP_TRY(once());
+        tn.panel_stamps = nullptr;
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(stamps_out, st.p, 64 * 8, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    A.release(); st.release(); info.release(); pristine.release();
+    return GPMI_OK;
+}
+
 int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
     return gpmi_probe_hbm_ex(c, bytes, 0, 2048, gbps);
 }

@@ -70,6 +70,13 @@ class GPContext:
         check(self._lib.gpmi_probe_gemm(self._h, M, N, K, lower, variant, reps, ptr(out)))
         return tuple(out)
 
+    def probe_panel(self, kind, m=0, reps=20, stamps=False):
+        """-> (microseconds per launch, stamps or None): potrf128 (kind 0) / trsm128 on m rows (kind 1) alone"""
+        us = C.c_double()
+        st = (C.c_uint64 * 64)() if stamps else None
+        check(self._lib.gpmi_probe_panel(self._h, int(kind), int(m), int(reps), C.byref(us), st))
+        return us.value, (np.array(st, dtype=np.uint64) if stamps else None)
+
     def probe_hbm_write(self, nbytes=1 << 30):
         v = C.c_double()
         check(self._lib.gpmi_probe_hbm_write(self._h, int(nbytes), C.byref(v)))

@@ -69,9 +69,12 @@ int gpmi_ctx_destroy(gpmi_ctx* ctx);
  * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
  *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "lanes" (factorisations in flight in
  *               gpmi_lml_batch, 0 = by size), "ramp" (0/1, default 0: block widths ramp up/down
- *               at the ends of the sweep when "nb" is automatic)
- * process-wide (kernel selection, for measurements): "gemm_dma" (0/1), "gemm_dma_waves" (4/8),
- *               "gemm_small_tiles" (0/1), "trsm_wave" (0/1), "rbf_blocks" (persistent blocks of the K build) */
+ *               at the ends of the sweep when "nb" is automatic);
+ *               kernel selection (for measurements; also per context -- the lanes of gpmi_lml_batch inherit them):
+ *               "panel_fused" (0/1: 128-column MFMA panel kernels / first-generation 64-column leaves),
+ *               "gemm_dma" (0/1), "gemm_dma_waves" (4/8), "gemm_small_tiles" (0/1), "trsm_wave" (0/1),
+ *               "rbf_blocks" (persistent blocks of the K build).
+ * The context-free gpmi_dev_* primitives run with the defaults. */
 int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);
 
 /* RBF_kernel(a, b, sigma, l)                         GP_regression.py:8-19
@@ -191,6 +194,10 @@ int gpmi_probe_hbm_write(gpmi_ctx* ctx, int64_t bytes, double* gbps);
 /* streaming bandwidth with a chosen access form: mode 0 grid-stride 16-byte stores, 1 the same
  * non-temporal, 2 one contiguous span per workgroup, 3 span + non-temporal, 4 16-byte loads */
 int gpmi_probe_hbm_ex(gpmi_ctx* ctx, int64_t bytes, int mode, int blocks, double* gbps);
+/* the panel kernels alone on scratch data: kind 0 = Cholesky of one 128 x 128 block (potrf128), kind 1 = X L^-T on
+ * m rows (trsm128); *out_us = microseconds per launch; stamps_out (64 entries or NULL) = in-kernel clock stamps
+ * of one instrumented launch (layout: csrc/panel_mfma.hip) */
+int gpmi_probe_panel(gpmi_ctx* ctx, int kind, int64_t m, int reps, double* out_us, uint64_t* stamps_out);
 
 /* ---------------------------------------------------------------------------
  * Device-pointer block primitives for the multi-GPU (row-block cyclic) driver
@@ -207,12 +214,16 @@ int gpmi_dev_rbf_rows(void* stream, const double* X_dev, int64_t N, int64_t d,
 int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const double* X_dev,
                        int64_t N, int64_t d, int64_t row0, int64_t nrows, int64_t ncols,
                        double sigma, double ell, double* out_dev, int64_t ld);
-/* in-place Cholesky of the nb x nb diagonal block (nb multiple of 64);
+/* in-place Cholesky of the nb x nb diagonal block (nb multiple of 128);
  * info_dev: int64 on the device, atomically min-ed with col_offset + failing
- * column (initialise to INT64_MAX). */
+ * column (initialise to INT64_MAX).  On return the lower triangle holds L; the strict upper triangles of
+ * the 16 x 16 tiles on the diagonal hold the transposed inverses of those tiles (storage nothing else reads),
+ * which gpmi_dev_trsm_block uses. */
 int gpmi_dev_potrf_block(void* stream, double* A_dev, int64_t ld, int64_t nb,
                          int64_t col_offset, int64_t* info_dev);
-/* X (m x nb, ldx) <- X * L^-T with L the nb x nb lower factor (ldl) */
+/* X (m x nb, ldx) <- X * L^-T with L the nb x nb lower factor (ldl) AS LEFT BY gpmi_dev_potrf_block / the
+ * factorisation (nb multiple of 128: the 16 x 16 diagonal tiles carry their inverses above the diagonal; a
+ * copy of the block must be a copy of the whole nb x nb square) */
 int gpmi_dev_trsm_block(void* stream, const double* L_dev, int64_t ldl, double* X_dev,
                         int64_t ldx, int64_t m, int64_t nb);
 /* C (M x N, ldc) -= A (M x K, lda) * B (N x K, ldb)^T.  lower != 0: only tiles

@@ -315,6 +315,70 @@ def test_bitwise_reproducible(ctx):
         assert np.array_equal(a, b)
 
 
+# ------------------------------------------------------------------ panel kernels
+@pytest.mark.parametrize("nb", [128, 256, 512])
+def test_fused_panel_kernels_vs_lapack(nb):
+    """potrf128 / trsm128 (MFMA panel kernels, 16 x 16 diagonal blocks factored and inverted in registers)
+    through the device-pointer primitives the multi-rank driver chains: Cholesky of an nb x nb block against
+    np.linalg.cholesky, X L^-T against scipy's triangular solve."""
+    import scipy.linalg as sla
+    import torch
+    from gaussian_process_amd.dist import HipBlockOps
+    ops = HipBlockOps(0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(nb)
+    B = rng.standard_normal((nb, nb + 7))
+    S = B @ B.T / nb + 0.05 * np.eye(nb)
+    info = torch.full((1,), (1 << 63) - 1, dtype=torch.int64, device=dev)
+    A = torch.zeros(nb, nb + 32, dtype=torch.float64, device=dev)
+    A[:, :nb].copy_(torch.from_numpy(S))
+    ops.potrf_block(A[:, :nb], 0, info)
+    torch.cuda.synchronize()
+    L = np.tril(A[:, :nb].cpu().numpy())
+    Lref = np.linalg.cholesky(S)
+    assert int(info.item()) == (1 << 63) - 1
+    assert np.max(np.abs(L - Lref)) <= 1e-13 * np.max(np.abs(Lref)) * np.linalg.cond(Lref)
+    assert np.max(np.abs(L @ L.T - S)) <= 1e-14 * np.max(np.abs(S)) * nb
+    for m in (128, 640):
+        X0 = rng.standard_normal((m, nb))
+        X = torch.zeros(m, nb + 32, dtype=torch.float64, device=dev)
+        X[:, :nb].copy_(torch.from_numpy(X0))
+        ops.trsm_block(A[:, :nb], X[:, :nb])
+        torch.cuda.synchronize()
+        got = X[:, :nb].cpu().numpy()
+        want = sla.solve_triangular(L, X0.T, lower=True).T
+        assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want)) * np.linalg.cond(L)
+        assert np.max(np.abs(got @ L.T - X0)) <= 1e-13 * np.max(np.abs(X0)) * nb
+    # a non-positive pivot is reported at its global column
+    S2 = S.copy()
+    S2[70, 70] = -1.0
+    A[:, :nb].copy_(torch.from_numpy(S2))
+    ops.potrf_block(A[:, :nb], 1000, info)
+    torch.cuda.synchronize()
+    assert int(info.item()) == 1000 + 70
+
+
+def test_first_generation_panel_kernels_still_agree(ctx, oracle):
+    """option panel_fused = 0 keeps the 64-column potf2 + substitution leaves: same answers to rounding."""
+    X, y, Xs = oracle.synthetic_problem(1500, 8, 64)
+    lml = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    mu, var = ctx.predict(Xs, want_sd=False)
+    ctx.set_option("panel_fused", 0)
+    try:
+        lml0 = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+        mu0, var0 = ctx.predict(Xs, want_sd=False)
+    finally:
+        ctx.set_option("panel_fused", 1)
+    assert abs(lml - lml0) <= 1e-11 * abs(lml0)          # two correct fp64 algorithms: cond x eps apart
+    assert np.max(np.abs(mu - mu0)) <= 1e-10 and np.max(np.abs(var - var0)) <= 1e-12
+    # a factor from the first-generation leaves has no inverses in its diagonal tiles: predict must not switch leaves
+    ctx.set_option("panel_fused", 0)
+    ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    ctx.set_option("panel_fused", 1)
+    mu1, var1 = ctx.predict(Xs, want_sd=False)
+    assert np.array_equal(mu1, mu0) and np.array_equal(var1, var0)
+
+
 # ------------------------------------------------------------------ larger sizes
 def test_mid_size_vs_oracle_N4096(ctx, oracle):
     X, y, Xs = oracle.synthetic_problem(4096, 8, 512)
