@@ -186,11 +186,13 @@ def tune_hyperparameters_BO(X_train, X_test, y_train, *, choices=('UBC', 'TS', '
     dim_parms = 11
     n_train_hyperparms = 5
     traces = {}
+    passes = []                     # per pass: the choice, the running maxima, the points the acquisition chose
     best = None
     for j in choices:
         hyperparms_train = init_hyperms(n_train_hyperparms, dim_parms)
         cache = {}
         y_axis = np.zeros(num_iterations)
+        chosen = []
         for k in range(num_iterations):
             hyperparms_test = random_sample_test_parms(n_hyperparms_test, hyperparms_train)
             lml = np.zeros(len(hyperparms_train))
@@ -205,8 +207,12 @@ def tune_hyperparameters_BO(X_train, X_test, y_train, *, choices=('UBC', 'TS', '
             best = hyperparms_train[int(np.argmax(lml))]
             if next_point is True:
                 break
-            hyperparms_train = np.append(hyperparms_train, [np.asarray(next_point).reshape(-1)], axis=0)   # :344
+            chosen.append(np.asarray(next_point, dtype=np.float64).reshape(-1))
+            hyperparms_train = np.append(hyperparms_train, [chosen[-1]], axis=0)   # :344
         traces[j] = y_axis
+        passes.append({"choice": j, "y_axis": y_axis, "chosen": np.array(chosen), "train": hyperparms_train})
+    if return_trace == "passes":
+        return best, passes
     if return_trace:
         return best, traces
     return best

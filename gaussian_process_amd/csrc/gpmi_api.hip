@@ -313,7 +313,12 @@ int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
     HIP_TRY(hipMemcpyAsync(x, c->A.as<double>() + c->Np * c->ldA, (size_t)c->Np * 8,
                            hipMemcpyDeviceToDevice, s));
     size_t sp = c->span_begin(GPMI_T_ALPHA);
-    HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), c->ldA, x, c->Np));
+    if (c->factor_fused) {
+        HIP_TRY(launch_trsv_lt_fused(s, c->A.as<double>(), c->ldA, x, x + c->Np, c->Np));
+        x += c->Np;
+    } else {
+        HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), c->ldA, x, c->Np));
+    }
     c->span_end(sp);
     HIP_TRY(hipMemcpyAsync(alpha_out, x, (size_t)c->N * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -433,7 +438,12 @@ int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
     // alpha = L^-T m (a5)
     double* alpha = c->vec.as<double>();
     HIP_TRY(hipMemcpyAsync(alpha, c->A.as<double>() + Np * ld, (size_t)Np * 8, hipMemcpyDeviceToDevice, s));
-    HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), ld, alpha, Np));
+    if (c->factor_fused) {
+        HIP_TRY(launch_trsv_lt_fused(s, c->A.as<double>(), ld, alpha, alpha + Np, Np));
+        alpha += Np;
+    } else {
+        HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), ld, alpha, Np));
+    }
     // U = I * L^-T
     double* U = c->U.as<double>();
     HIP_TRY(launch_fill_rows(s, U, ld, Np, Np, 0.0));

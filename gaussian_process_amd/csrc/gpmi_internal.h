@@ -157,6 +157,9 @@ hipError_t launch_logdiag_sumsq(hipStream_t s, const double* A, int64_t ld, int6
                                 int64_t nx, double* out2);
 // backward substitution  L^T x = b  (x overwrites b); n multiple of 64
 hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b, int64_t n);
+// the same for a factor left by the fused panel kernels (inverses in the diagonal tiles), 128 unknowns per
+// launch; n multiple of 128; b is destroyed, the solution goes to xout (must not alias b)
+hipError_t launch_trsv_lt_fused(hipStream_t s, const double* L, int64_t ld, double* b, double* xout, int64_t n);
 // y[c] = sum_r A[r][c] * x[r]; scratch: ceil(nrows/64) * ncols doubles
 hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nrows, int64_t ncols,
                          const double* x, double* y, double* scratch);

@@ -281,6 +281,169 @@ def acquisition_cases():
     np.savez_compressed(os.path.join(OUT, "kernels_acq.npz"), **out)
 
 
+def py2_functions(path, names, namespace):
+    """ref_functions for def blocks that contain Python-2 print statements / backtick repr: lib2to3's print and
+    repr fixers run over the block's text (in memory, in this container only), then the text is executed."""
+    import re
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from lib2to3.refactor import RefactoringTool
+        tool = RefactoringTool(["lib2to3.fixes.fix_print", "lib2to3.fixes.fix_repr"])
+    text = open(path, newline=None).read()
+    for name in names:
+        m = re.search(r"^def %s\(.*?(?=^\S|\Z)" % re.escape(name), text, re.S | re.M)
+        src = str(tool.refactor_string(m.group(0).rstrip("\n") + "\n", name))
+        exec(compile(src, "%s:%s" % (path, name), "exec"), namespace)
+    return namespace
+
+
+class Py3Random:
+    """`random` as the reference's functions see it: Python 3's random.sample refuses an ndarray population
+    (tune_hyperparms_regression.py:343, CO2_example.py:121), so sample() lists it first -- the drop-ins make the
+    same call.  Everything else is the module's own."""
+    def __init__(self):
+        import random
+        self._r = random
+
+    def sample(self, population, k):
+        return self._r.sample(list(population), k)
+
+    def __getattr__(self, name):
+        return getattr(self._r, name)
+
+
+class NpCompat:
+    """`np` as the reference's 2017-era code expects it: np.delete accepted the float-typed EMPTY index array
+    that overlap() returns when nothing overlaps (tune_hyperparms_regression.py:328, 342); NumPy 2 raises
+    IndexError for it.  Only that call is adapted (index array cast to int, what the drop-ins do); every other
+    attribute is NumPy's own."""
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def delete(arr, obj, axis=None):
+        obj = np.asarray(obj)
+        if obj.dtype.kind == "f":
+            obj = obj.astype(int)
+        return np.delete(arr, obj, axis)
+
+
+class Recorder:
+    """stand-in for print inside executed reference code: keeps what was printed"""
+    def __init__(self):
+        self.items = []
+
+    def __call__(self, *args):
+        self.items.append(args[0] if len(args) == 1 else args)
+
+
+def bo_loop_cases():
+    """SURVEY.md section 8f row f3, the parts with Python-2 prints: PI (:165-204), random_gen_test_parms (:331-346),
+    tune_hyperparms_second (:349-395) of tune_hyperparms_regression.py and tune_hyperparameters_BO
+    (CO2_example.py:309-371), executed from the reference's own source through lib2to3 (print / repr fixers
+    only) with seeded `random` and `np.random`.  Plot calls go to a throw-away Agg figure, plot_BO is a no-op."""
+    import random
+    from scipy.stats import norm
+    import matplotlib.pyplot as plt
+    rnd = Py3Random()
+    rec = Recorder()
+    npc = NpCompat()
+    ns = {"np": npc, "norm": norm, "plt": plt, "random": rnd, "RBF_kernel": REF.RBF_kernel,
+          "prediction": REF.prediction, "print": rec, "plot_BO": lambda *a, **k: None}
+    path = "/root/reference/tune_hyperparms_regression.py"
+    ref_functions(path, ["compute_mar_likelihood", "bayesian_opt", "UCB", "EI", "TS", "overlap", "acquisition_fun"], ns)
+    py2_functions(path, ["PI", "random_gen_test_parms", "tune_hyperparms_second"], ns)
+    out = {}
+    # ---- PI alone (three situations: a unique maximiser, ties broken by random.randint, the early stop)
+    rng = np.random.default_rng(191)
+    done = np.array([0.4, 1.1, 2.3, 3.1, 4.6])
+    y = np.array([-310.2, 210.5, 402.75, 380.1, 150.9])
+    params = np.sort(rng.uniform(0.02, 5, 60)).reshape(-1, 1)
+    np.random.seed(21)
+    mu, sd, _ = ns["bayesian_opt"](done.reshape(-1, 1), params, y)
+    random.seed(7)
+    out.update(pi_done=done, pi_y=y, pi_params=params, pi_mu=mu, pi_sd=sd,
+               pi_next=np.asarray(ns["PI"](params, mu, sd, done, y, 3, 0)))
+    mu_t = mu.copy(); mu_t[[5, 17, 40]] = 1e4                       # three candidates with cdf == 1: a tie
+    random.seed(8)
+    out.update(pi_mu_tie=mu_t, pi_next_tie=np.asarray(ns["PI"](params, mu_t, sd, done, y, 3, 0)))
+    out["pi_stop"] = np.asarray(ns["PI"](params, mu - 1e4, sd, done, y, 3, 0) is True)
+    # ---- random_gen_test_parms
+    random.seed(11)
+    out["rg_done"] = np.array([0.5, 3.5, 0.01, 5.0])
+    out["rg_out"] = ns["random_gen_test_parms"](100, out["rg_done"])
+    # ---- the loop: every surrogate fit, candidate set and chosen point of each iteration
+    np.random.seed(3)
+    f, X, yv, Xs = REF.dataset_generator(60, 25)
+    log = {"bo": [], "cand": [], "next": []}
+    bo, gen, acq = ns["bayesian_opt"], ns["random_gen_test_parms"], ns["acquisition_fun"]
+
+    def bo_rec(lt, lq, yl):
+        r = bo(lt, lq, yl)
+        log["bo"].append((lt.copy(), lq.copy(), yl.copy(), r[0].copy(), r[1].copy()))
+        return r
+
+    def gen_rec(n, done_):
+        r = gen(n, done_)
+        log["cand"].append(r.copy())
+        return r
+
+    def acq_rec(*a):
+        r = acq(*a)
+        log["next"].append(r)
+        return r
+    ns.update(bayesian_opt=bo_rec, random_gen_test_parms=gen_rec, acquisition_fun=acq_rec)
+    l0 = np.array([0.5, 3.5])
+    random.seed(5); np.random.seed(5)
+    best = ns["tune_hyperparms_second"](X, Xs, yv, 1, 1, l0.copy())
+    out.update(lp_X=X, lp_y=yv, lp_Xs=Xs, lp_l0=l0, lp_best=best, lp_iters=len(log["next"]))
+    for k, (lt, lq, yl, m_, s_) in enumerate(log["bo"]):
+        out.update({"lp%d_l" % k: lt.reshape(-1), "lp%d_cand" % k: lq, "lp%d_lml" % k: yl, "lp%d_mu" % k: m_,
+                    "lp%d_sd" % k: s_})
+    for k, nx in enumerate(log["next"]):
+        out["lp%d_next" % k] = np.asarray(-1.0 if nx is True else np.ravel(nx)[0])
+    out["lp_printed"] = np.array([str(i) for i in rec.items])
+    # ---- CO2_example.tune_hyperparameters_BO
+    rec2 = Recorder()
+    ns2 = {"np": npc, "norm": norm, "plt": plt, "random": rnd, "print": rec2}
+    cpath = "/root/reference/CO2_example.py"
+    ref_functions(cpath, ["kernel_1", "kernel_2", "kernel_3", "kernel_4", "covariance_function", "compute_mar_likelihood",
+                          "bayesian_opt", "UBC", "TS", "EI", "PI", "acquisition_fun", "init_hyperms"], ns2)
+    ns2["overlap"] = ns["overlap"]                 # CO2_example.py:1 imports it from tune_hyperparms_regression
+    py2_functions(cpath, ["random_sample_test_parms", "tune_hyperparameters_BO"], ns2)
+    rng = np.random.default_rng(78)
+    Xc = (1958.0 + np.arange(240) / 12.0 + 0.04).reshape(-1, 1)
+    yc = 0.11 * (Xc[:, 0] - 1958) ** 1.5 + 3 * np.sin(2 * np.pi * Xc[:, 0]) + 0.3 * rng.standard_normal(240)
+    yc = yc - np.mean(yc)
+    clog = {"bo": [], "next": []}
+    cbo, cacq = ns2["bayesian_opt"], ns2["acquisition_fun"]
+
+    def cbo_rec(ht, hq, yl):
+        r = cbo(ht, hq, yl)
+        clog["bo"].append((ht.copy(), hq[:3].copy(), float(hq.sum()), yl.copy(), r[0].copy(), r[1].copy()))
+        return r
+
+    def cacq_rec(*a):
+        r = cacq(*a)
+        clog["next"].append(np.asarray(r).copy())
+        return r
+    ns2.update(bayesian_opt=cbo_rec, acquisition_fun=cacq_rec)
+    random.seed(9); np.random.seed(9)
+    plt.figure()
+    best_h = ns2["tune_hyperparameters_BO"](Xc, Xc[:5], yc)
+    plt.close("all")
+    out.update(co_X=Xc, co_y=yc, co_best=best_h, co_steps=len(clog["next"]))
+    out["co_next"] = np.array(clog["next"])                                    # (40, 11): 4 passes x 10 iterations
+    out["co_ymax"] = np.array([b[3].max() for b in clog["bo"]])                # what the reference prints per iteration
+    out["co_cand_head"] = np.array([b[1] for b in clog["bo"]])                 # first 3 candidates of every iteration
+    out["co_cand_sum"] = np.array([b[2] for b in clog["bo"]])
+    for k in (0, 9, 10, 39):                                                   # surrogate posteriors of four iterations
+        out.update({"co%d_train" % k: clog["bo"][k][0], "co%d_lml" % k: clog["bo"][k][3], "co%d_mu" % k: clog["bo"][k][4],
+                    "co%d_sd" % k: clog["bo"][k][5]})
+    np.savez_compressed(os.path.join(OUT, "kernels_bo_loops.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     for sd_ in (0, 1, 2):
@@ -294,4 +457,5 @@ if __name__ == "__main__":
     grad_cases()
     bo_and_co2_cases()
     acquisition_cases()
+    bo_loop_cases()
     print("wrote", sorted(os.listdir(OUT)))

@@ -120,3 +120,38 @@ def test_co2_host_functions_vs_reference_source():
     cand = C2.random_sample_test_parms(20, g["co2_hp"])
     assert cand.shape == (20, 11)
     assert np.all(cand >= 0.3 * C2.HYPERMS_BOOK - 1e-12) and np.all(cand <= 1.5 * C2.HYPERMS_BOOK + 1e-12)
+
+
+# ---- host-only pieces of the BO loop against vectors produced by EXECUTING the reference's
+# own Python-2 source (lib2to3 print/repr fixers, oracle/make_golden.py bo_loop_cases)
+def test_PI_and_candidate_sampling_vs_reference_source():
+    import random
+    from conftest import golden
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    g = golden("kernels_bo_loops")
+    random.seed(7)
+    got = T.PI(g["pi_params"], g["pi_mu"], g["pi_sd"], g["pi_done"], g["pi_y"], 3, 0)
+    assert np.array_equal(np.ravel(got), np.ravel(g["pi_next"]))
+    random.seed(8)                                   # three candidates tie at cdf == 1: random.randint picks
+    got = T.PI(g["pi_params"], g["pi_mu_tie"], g["pi_sd"], g["pi_done"], g["pi_y"], 3, 0)
+    assert np.array_equal(np.ravel(got), np.ravel(g["pi_next_tie"]))
+    assert T.PI(g["pi_params"], g["pi_mu"] - 1e4, g["pi_sd"], g["pi_done"], g["pi_y"], 3, 0) is True and bool(g["pi_stop"])
+    random.seed(11)
+    out = T.random_gen_test_parms(100, g["rg_done"])
+    assert out.shape == (100, 1) and np.array_equal(out, g["rg_out"])
+
+
+def test_bo_loop_decisions_vs_reference_source_given_its_surrogate():
+    """Every iteration of the reference's tune_hyperparms_second run: fed the reference's own surrogate mean / sd
+    and candidate set, the drop-in's acquisition picks the reference's next lengthscale (host logic only)."""
+    import random
+    from conftest import golden
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    g = golden("kernels_bo_loops")
+    random.seed(5)
+    for k in range(int(g["lp_iters"])):
+        cand = T.random_gen_test_parms(100, g["lp%d_l" % k])
+        assert np.array_equal(cand, g["lp%d_cand" % k])          # same random.sample stream as the reference
+        nxt = T.PI(cand, g["lp%d_mu" % k], g["lp%d_sd" % k], g["lp%d_l" % k], g["lp%d_lml" % k], 3, k)
+        want = float(g["lp%d_next" % k])
+        assert (nxt is True and want < 0) or float(np.ravel(nxt)[0]) == want

@@ -760,3 +760,56 @@ def test_lml_batch_lanes_are_bitwise_equivalent(oracle, N):
         want = oracle.compute_mar_likelihood(X2, None, y2, triples[t, 1], triples[t, 0], s=triples[t, 2])
         assert abs(l3[t] - want) <= LML_RTOL * abs(want)
     c.close()
+
+
+# ---- f3: the BO loops against the reference's own loops (executed from source through lib2to3, fixtures in
+# kernels_bo_loops.npz; oracle/make_golden.py bo_loop_cases)
+def test_tune_hyperparms_second_vs_reference_run(ctx):
+    """tune_hyperparms_regression.py:349-395 free-running with the reference's seeds: the same lengthscales are
+    chosen in the same order, every LML and surrogate posterior agrees, the returned maximum agrees."""
+    import random
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    g = golden("kernels_bo_loops")
+    X, y, Xs = g["lp_X"], g["lp_y"], g["lp_Xs"]
+    iters = int(g["lp_iters"])
+    # teacher-forced: each iteration's LMLs and surrogate posterior from the reference's state
+    for k in range(iters):
+        ls = g["lp%d_l" % k]
+        lml = np.array([T.compute_mar_likelihood(X, Xs, y, 1, l, ctx=ctx) for l in ls])
+        assert np.max(np.abs(lml - g["lp%d_lml" % k]) / np.abs(g["lp%d_lml" % k])) <= LML_RTOL
+        np.random.seed(0)
+        mu, sd, _ = T.bayesian_opt(ls.reshape(-1, 1), g["lp%d_cand" % k], g["lp%d_lml" % k], ctx=ctx)
+        scale = np.max(np.abs(g["lp%d_lml" % k]))
+        assert np.max(np.abs(mu - g["lp%d_mu" % k])) <= 1e-8 * scale
+        assert np.max(np.abs(sd - g["lp%d_sd" % k])) <= 1e-7
+    # free-running
+    random.seed(5)
+    np.random.seed(5)
+    best, ls, lmls = T.tune_hyperparms_second(X, Xs, y, 1, 1, g["lp_l0"].copy(), ctx=ctx, return_trace=True)
+    want_l = np.concatenate([g["lp_l0"], [float(g["lp%d_next" % k]) for k in range(iters) if float(g["lp%d_next" % k]) >= 0]])
+    assert np.array_equal(ls, want_l)
+    assert abs(best - float(g["lp_best"])) <= LML_RTOL * abs(float(g["lp_best"]))
+
+
+def test_co2_tune_hyperparameters_BO_vs_reference_run(ctx):
+    """CO2_example.py:309-371 (4 passes x 10 iterations, 500 candidates in 11 dimensions; the reference hands the whole
+    `choice` list to acquisition_fun, so every pass is PI) free-running with the reference's seeds: same candidates,
+    same chosen hyper-parameter vectors, same running maxima, same returned vector."""
+    import random
+    from gaussian_process_amd import CO2_example as C2
+    g = golden("kernels_bo_loops")
+    X, y = g["co_X"], g["co_y"]
+    # teacher-forced surrogate posteriors of four iterations
+    for k in (0, 9, 10, 39):
+        tr, lml = g["co%d_train" % k], g["co%d_lml" % k]
+        got = np.array([C2.compute_mar_likelihood(X, y, h, ctx=ctx) for h in tr])
+        assert np.max(np.abs(got - lml) / np.abs(lml)) <= 1e-9
+    random.seed(9)
+    np.random.seed(9)
+    best, passes = C2.tune_hyperparameters_BO(X, X[:5], y, choices=("PI",) * 4, ctx=ctx, return_trace="passes")
+    chosen = np.concatenate([p["chosen"] for p in passes])
+    ymax = np.concatenate([p["y_axis"] for p in passes])
+    assert chosen.shape == g["co_next"].shape
+    assert np.array_equal(chosen, g["co_next"])
+    assert np.max(np.abs(ymax - g["co_ymax"]) / np.abs(g["co_ymax"])) <= 1e-9
+    assert np.array_equal(best, g["co_best"])
