@@ -69,6 +69,7 @@ SIGNATURES = {
     "gpmi_dev_gemm_nt": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64],
     "gpmi_dev_gemm_nt_rowmap": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64],
     "gpmi_dev_gemm_nt_rowmap_host": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64],
+    "gpmi_dev_gemm_nt_blocks": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _i64],
     "gpmi_dev_logdiag_sumsq": [_vp, _vp, _i64, _i64, _vp, _i64, _vp],
     "gpmi_dev_gemv_t": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
     "gpmi_dev_trsv_lt": [_vp, _vp, _i64, _vp, _i64],

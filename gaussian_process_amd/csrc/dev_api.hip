@@ -100,6 +100,34 @@ int gpmi_dev_gemm_nt_rowmap_host(void* stream, double* C_dev, int64_t ldc, const
     return GPMI_OK;
 }
 
+// The row-map update with B given as a table of row blocks: block i of B (b_block_rows x K, leading dimension
+// ldb) starts at B_dev + b_block_off_dev[i] doubles.  This is how the multi-rank driver reads the panel column
+// straight out of the all-gather's receive buffer (one contiguous chunk per rank) in natural block order,
+// with no re-ordering copy.  row_ncols_dev / row_ncols_host may both be NULL (plain rectangle).
+int gpmi_dev_gemm_nt_blocks(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                            const double* B_dev, int64_t ldb, const int64_t* b_block_off_dev, int64_t b_block_rows,
+                            int64_t M, int64_t N, int64_t K, const int32_t* row_ncols_dev,
+                            const int32_t* row_ncols_host, int64_t row_bands, int64_t row_block_rows) {
+    if (!C_dev || !A_dev || !B_dev || !b_block_off_dev) return fail_arg("gpmi_dev_gemm_nt_blocks: null pointer");
+    if (M < 0 || N < 0 || K < 0 || M % TILE || N % TILE || K % 16 || K < 32 || ldc % 2 || lda % 2 || ldb % 2 ||
+        b_block_rows <= 0 || b_block_rows % TILE)
+        return fail_arg("gpmi_dev_gemm_nt_blocks: M%128, N%128, K%16 (K >= 32), b_block_rows%128 must be 0");
+    if ((row_ncols_dev != nullptr) != (row_ncols_host != nullptr))
+        return fail_arg("gpmi_dev_gemm_nt_blocks: the row map needs both its device and its host copy");
+    if (row_ncols_dev && (row_block_rows <= 0 || row_block_rows % TILE || row_bands * row_block_rows < M))
+        return fail_arg("gpmi_dev_gemm_nt_blocks: row_block_rows%128 must be 0 and the map must cover M");
+    GemmArgs g;
+    g.C = C_dev; g.A = A_dev; g.B = B_dev; g.ldc = ldc; g.lda = lda; g.ldb = ldb;
+    g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = 0; g.diag_off = 0;
+    g.b_block_off = b_block_off_dev; g.b_block_rows = b_block_rows;
+    if (row_ncols_dev) {
+        g.row_ncols = row_ncols_dev; g.row_block_tiles = (int)(row_block_rows / TILE);
+        g.row_ncols_host = row_ncols_host; g.row_bands = (int)row_bands;
+    }
+    HIP_TRY(launch_gemm_nt((hipStream_t)stream, g));
+    return GPMI_OK;
+}
+
 int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
                            int64_t nx, double* out2_dev) {
     if (!out2_dev) return fail_arg("gpmi_dev_logdiag_sumsq: null output");

@@ -46,6 +46,8 @@ struct GemmDmaDev {
     int64_t diag_off;
     const int32_t* row_ncols;
     int row_block_tiles;
+    const int64_t* b_block_off;   // B as a table of row blocks (see GemmArgs), or null
+    int b_block_tiles;            // 128-row tiles per block
     int S, logS, SM, SN, tri, nsuper;
     // tri == 2: staircase (row map with a host copy): supertile row si holds sprefix[si+1] - sprefix[si]
     // live supertiles, its leftmost ones; only those are enumerated
@@ -129,7 +131,12 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
     const int drow = lane >> 3;
     const int dkp = (lane & 7) ^ (drow & 7);
     const double* a_src = p.A + ((int64_t)ti * DMA_TM + RPW * wave + drow) * p.lda + dkp * 2;
-    const double* b_src = p.B + ((int64_t)tj * DMA_TN + RPW * wave + drow) * p.ldb + dkp * 2;
+    int64_t b_row0 = (int64_t)tj * DMA_TN * p.ldb;
+    if (p.b_block_off) {                 // wave-uniform: one scalar load
+        const int blk = tj / p.b_block_tiles;
+        b_row0 = p.b_block_off[blk] + (int64_t)(tj - blk * p.b_block_tiles) * DMA_TN * p.ldb;
+    }
+    const double* b_src = p.B + b_row0 + (int64_t)(RPW * wave + drow) * p.ldb + dkp * 2;
     const int64_t a_step = 8 * p.lda, b_step = 8 * p.ldb;
     GPMI_LDS char* lds = (GPMI_LDS char*)smem_raw;
     const int a_dst = (RPW * wave) * 128;                        // byte offset inside a stage
@@ -332,6 +339,9 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     p.nchunks = (int)(a.K / 16);
     p.lower = a.lower; p.diag_off = a.diag_off;
     p.row_ncols = a.row_ncols; p.row_block_tiles = a.row_block_tiles > 0 ? a.row_block_tiles : 1;
+    p.b_block_off = a.b_block_off;
+    p.b_block_tiles = a.b_block_off ? (int)(a.b_block_rows / 128) : 1;
+    if (a.b_block_off && (a.b_block_rows <= 0 || a.b_block_rows % 128)) return hipErrorInvalidValue;
     p.tri = (a.lower && a.diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
     const bool stairs = a.row_ncols && a.row_ncols_host && a.row_bands > 0 && !a.lower;
     int S = 8;

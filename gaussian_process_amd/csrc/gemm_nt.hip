@@ -259,6 +259,7 @@ static void plan(const GemmArgs& a, int TM, int TN, GemmDev& p, int& nblocks) {
 bool gemm_nt_routes_dma(const GemmArgs& a) {
     // ablation bits >= 256 select the DMA kernel's ablations (low byte passed on)
     const Tuning& tn = tuning();
+    if (a.b_block_off) return true;            // only the LDS-DMA kernel reads B through a block table
     return tn.gemm_use_dma && (!tn.gemm_dbg || tn.gemm_dbg >= 256) && gemm_dma_eligible(a) &&
            (a.M / 128) * (a.N / 128) >= 256;
 }
@@ -266,6 +267,7 @@ bool gemm_nt_routes_dma(const GemmArgs& a) {
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return hipSuccess;
     if (a.M % 128 || a.N % 64 || a.K % BK) return hipErrorInvalidValue;
+    if (a.b_block_off && !gemm_dma_eligible(a)) return hipErrorInvalidValue;
     if (gemm_nt_routes_dma(a)) return launch_gemm_nt_dma(s, a);
     GemmDev p;
     int nblocks;

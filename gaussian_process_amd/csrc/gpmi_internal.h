@@ -73,6 +73,11 @@ struct GemmArgs {
     const int32_t* row_ncols_host = nullptr;
     int row_bands = 0;
     int role = 0;   // 1: Cholesky trailing update (launched under its own kernel symbol)
+    // optional: B is not one matrix but a sequence of b_block_rows-row blocks (each b_block_rows x K, leading
+    // dimension ldb) at B + b_block_off[i] doubles -- the panel column exactly as an all-gather leaves it, one
+    // contiguous chunk per rank, read in natural block order through this table (device pointer); LDS-DMA kernel only
+    const int64_t* b_block_off = nullptr;
+    int64_t b_block_rows = 0;
 };
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a);
 bool gemm_nt_routes_dma(const GemmArgs& a);

@@ -153,32 +153,71 @@ hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b,
 // For a factor left by the fused panel kernels (panel_mfma.hip): every diagonal 16 x 16 tile carries its inverse,
 // transposed, above its diagonal (W[r][c] at tile[c][r], r > c; diag(W) = 1 / diag(L)), so the solve of a
 // diagonal block is a short sequence of 16 x 16 matrix-vector products instead of 128 dependent divisions.
-// One launch per 128-row block j, from the bottom up:
-//   A  every workgroup (redundantly -- the block is L2-resident after the first touch) loads L_jj into LDS and
-//      solves  L_jj^T x_j = b_j :  for s = 7..0:  x_s = W_ss^T r_s;  r_t -= L_st^T x_s  (t < s)
-//   B  b[c] -= sum_r L[j0 + r][c] x_j[r]  for the workgroup's 256 columns c < j0: the HBM-bound part, row
-//      segments of 2 KiB, 16-byte loads, the two halves of the workgroup take 64 rows each and are summed in a
-//      fixed order.
-// x goes to a separate vector (every workgroup reads b_j while workgroup 0 publishes x_j).
+// One launch per 128-row block, from the bottom up.  Launch j0 finds x_j (the solution of rows j0 .. j0 + 127)
+// in xout and does
+//   B  b[c] -= sum_r L[j0 + r][c] x_j[r]  for all columns c < j0 -- the HBM-bound part: 256 columns per
+//      workgroup, row segments of 2 KiB, 16-byte loads, the two halves of the workgroup take 64 rows each and
+//      are summed in a fixed order;
+//   A  workgroup 0 owns the columns next to the diagonal: once they are updated it solves the NEXT diagonal
+//      block,  L_kk^T x_k = b_k  (k = j - 1):  for s = 7..0:  x_s = W_ss^T r_s;  r_t -= L_st^T x_s  (t < s),
+//      and publishes x_k for the next launch -- the latency of the small solve hides behind the other
+//      workgroups' streaming.
+// The first launch (j0 = n) only solves the last block.  x goes to its own vector.
 // Replaces 2 x (n / 64) dependent launches of 64 unknowns each; reads the triangle once: 8 n (n + 1) / 2 bytes.
 constexpr int TS_LD = 130;       // doubles per LDS row of the diagonal block (conflict-free row and column walks)
 
 __global__ __launch_bounds__(256) void trsv_lt_step128_kernel(const double* __restrict__ L, int64_t ld, double* b,
-                                                               double* xout, int64_t j0) {
+                                                               double* xout, int64_t j0, int64_t n) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* Ls = sm;                       // 128 x TS_LD
-    double* rs = sm + 128 * TS_LD;         // residual / solution of the block
-    double* part = rs + 128;               // 256 partial sums (phase B)
+    double* Ls = sm;                       // 128 x TS_LD: the next diagonal block (workgroup 0 only)
+    double* xs = sm + 128 * TS_LD;         // x_j
+    double* rs = xs + 128;                 // residual / solution of the next block
+    double* part = rs + 128;               // 256 partial sums
     const int tid = threadIdx.x;
-    // ---- A: the diagonal block (lower triangle + the diagonal tiles' upper parts)
-    const double* Ljj = L + j0 * ld + j0;
-    for (int r = tid >> 2; r < 128; r += 64) {                 // 4 threads per row, 16-byte pieces
-        const int ncol = 16 * (r / 16 + 1);
-        for (int c = 2 * (tid & 3); c < ncol; c += 8)
-            *reinterpret_cast<d2*>(Ls + r * TS_LD + c) = *reinterpret_cast<const d2*>(Ljj + (int64_t)r * ld + c);
+    const int64_t nchunks = (j0 + 255) / 256;
+    const int64_t chunk = nchunks - 1 - (int64_t)blockIdx.x;      // workgroup 0 takes the columns next to the diagonal
+    const bool solver = blockIdx.x == 0 && j0 >= 128;
+    const int64_t k0 = j0 - 128;                                  // first row of the next diagonal block
+    // the next diagonal block is requested first: its latency hides behind the update below
+    if (solver) {
+        const double* Lkk = L + k0 * ld + k0;
+        for (int r = tid >> 2; r < 128; r += 64) {                // 4 threads per row, 16-byte pieces
+            const int ncol = 16 * (r / 16 + 1);
+#pragma unroll 4
+            for (int c = 2 * (tid & 3); c < ncol; c += 8)
+                *reinterpret_cast<d2*>(Ls + r * TS_LD + c) = *reinterpret_cast<const d2*>(Lkk + (int64_t)r * ld + c);
+        }
     }
-    if (tid < 128) rs[tid] = b[j0 + tid];
+    if (j0 < n) {
+        if (tid < 128) xs[tid] = xout[j0 + tid];
+        __syncthreads();
+        const int64_t c = chunk * 256 + 2 * (tid & 127);
+        const int half = tid >> 7;
+        double a0 = 0., a1 = 0.;
+        if (c < j0) {
+            const double* col = L + (j0 + 64 * half) * ld + c;
+            const double* xh = xs + 64 * half;
+#pragma unroll 16
+            for (int r = 0; r < 64; ++r) {
+                const d2 v = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+                a0 = fma(v.x, xh[r], a0);
+                a1 = fma(v.y, xh[r], a1);
+            }
+        }
+        if (half) { part[2 * (tid & 127)] = a0; part[2 * (tid & 127) + 1] = a1; }
+        __syncthreads();
+        if (!half && c < j0) {
+            const d2 bv = *reinterpret_cast<const d2*>(b + c);
+            const d2 nv = d2{bv.x - (a0 + part[2 * tid]), bv.y - (a1 + part[2 * tid + 1])};
+            *reinterpret_cast<d2*>(b + c) = nv;
+            if (solver && c >= k0) { rs[c - k0] = nv.x; rs[c - k0 + 1] = nv.y; }
+        }
+    } else if (solver && tid < 128) {
+        rs[tid] = b[k0 + tid];
+    }
+    if (!solver) return;
     __syncthreads();
+    // ---- A: L_kk^T x_k = r, one wave
     if (tid < 64) {
         const int lane = tid;
         for (int s = 7; s >= 0; --s) {
@@ -209,42 +248,22 @@ __global__ __launch_bounds__(256) void trsv_lt_step128_kernel(const double* __re
         }
     }
     __syncthreads();
-    if (blockIdx.x == 0 && tid < 128) xout[j0 + tid] = rs[tid];
-    // ---- B: this workgroup's 256 columns
-    const int64_t c = (int64_t)blockIdx.x * 256 + 2 * (tid & 127);
-    const int half = tid >> 7;
-    double a0 = 0., a1 = 0.;
-    if (c < j0) {
-        const double* col = L + (j0 + 64 * half) * ld + c;
-        const double* xs = rs + 64 * half;
-#pragma unroll 16
-        for (int r = 0; r < 64; ++r) {
-            const d2 v = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
-            a0 = fma(v.x, xs[r], a0);
-            a1 = fma(v.y, xs[r], a1);
-        }
-    }
-    if (half) { part[2 * (tid & 127)] = a0; part[2 * (tid & 127) + 1] = a1; }
-    __syncthreads();
-    if (!half && c < j0) {
-        const d2 bv = *reinterpret_cast<const d2*>(b + c);
-        *reinterpret_cast<d2*>(b + c) = d2{bv.x - (a0 + part[2 * tid]), bv.y - (a1 + part[2 * tid + 1])};
-    }
+    if (tid < 128) xout[k0 + tid] = rs[tid];
 }
 
 // Solves L^T x = b for a factor whose diagonal tiles carry their inverses (n % 128 == 0); b is destroyed,
 // the solution lands in xout (n doubles, may not alias b).
 hipError_t launch_trsv_lt_fused(hipStream_t s, const double* L, int64_t ld, double* b, double* xout, int64_t n) {
-    if (n % 128 || ld % 2) return hipErrorInvalidValue;
-    constexpr size_t lds = (size_t)(128 * TS_LD + 128 + 256) * sizeof(double);
+    if (n <= 0 || n % 128 || ld % 2) return hipErrorInvalidValue;
+    constexpr size_t lds = (size_t)(128 * TS_LD + 128 + 128 + 256) * sizeof(double);
     static PerDeviceOnce once;
     const hipError_t ea = once.run([&]() -> hipError_t {
         return hipFuncSetAttribute((const void*)trsv_lt_step128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     });
     if (ea != hipSuccess) return ea;
-    for (int64_t j0 = n - 128; j0 >= 0; j0 -= 128) {
-        const unsigned blocks = (unsigned)std::max<int64_t>(1, (j0 + 255) / 256);
-        hipLaunchKernelGGL(trsv_lt_step128_kernel, dim3(blocks), dim3(256), lds, s, L, ld, b, xout, j0);
+    for (int64_t j0 = n; j0 >= 128; j0 -= 128) {
+        const unsigned blocks = (j0 == n) ? 1u : (unsigned)((j0 + 255) / 256);     // the first launch only solves
+        hipLaunchKernelGGL(trsv_lt_step128_kernel, dim3(blocks), dim3(256), lds, s, L, ld, b, xout, j0, n);
     }
     return hipGetLastError();
 }

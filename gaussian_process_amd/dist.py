@@ -103,6 +103,17 @@ class HipBlockOps:
                                                self._p(B), self._ld(B), Cm.shape[0], Cm.shape[1], A.shape[1],
                                                C.c_void_p(row_ncols.data_ptr()), row_block_rows))
 
+    def gemm_nt_blocks(self, Cm, A, Bflat, ldb, boff, brows, row_ncols=None, row_block_rows=128, row_ncols_host=None):
+        """Cm -= A * B^T with B = the row blocks (brows x K, leading dimension ldb) at Bflat[boff[i]:] -- the
+        all-gather's receive buffer read in natural block order; optional row map as in gemm_nt_rowmap"""
+        assert boff.dtype == torch.int64 and boff.is_contiguous() and boff.shape[0] * brows >= Cm.shape[1]
+        check(self.lib.gpmi_dev_gemm_nt_blocks(
+            self._stream(), self._p(Cm), self._ld(Cm), self._p(A), self._ld(A), self._p(Bflat), int(ldb),
+            C.c_void_p(boff.data_ptr()), int(brows), Cm.shape[0], Cm.shape[1], A.shape[1],
+            C.c_void_p(row_ncols.data_ptr()) if row_ncols is not None else None,
+            C.c_void_p(row_ncols_host.ctypes.data) if row_ncols_host is not None else None,
+            row_ncols_host.shape[0] if row_ncols_host is not None else 0, row_block_rows))
+
     def logdiag_sumsq(self, A, n, x, nx, out2):
         check(self.lib.gpmi_dev_logdiag_sumsq(self._stream(), self._p(A) if A is not None else None,
                                               self._ld(A) if A is not None else 0, n,
@@ -194,11 +205,27 @@ class DistGP:
         self.A = self._tensor(max(self.rows, 1), self.ld)
         self.Lkk = self._tensor(NB, NB)
         cmax = max(self._nblocks(r) for r in range(G))
-        self.send = self._tensor(max(cmax, 1) * NB, NB)
-        self.recv = self._tensor(G * max(cmax, 1) * NB, NB)
+        self.send = self._tensor(max(cmax, 1) * NB * NB)
         self.Lk = [self.Lkk, self._tensor(NB, NB)]
-        self.Pbuf = [self._tensor(max(self.T - 1, 1) * NB, NB) for _ in range(2 if self.lookahead else 1)] \
+        # The panel column of a step lives where the all-gather delivers it: one contiguous chunk per rank
+        # (rank r's solved blocks below k, in its local order).  Nothing re-orders it: the update kernels read
+        # the blocks in natural order through a per-step offset table (block k+1+i -> chunk of rank
+        # (k+1+i) % G, position among that rank's blocks below k).  Two buffers: panel k+1 is gathered while
+        # the update with panel k still runs (lookahead).
+        self.Pbuf = [self._tensor(G * max(cmax, 1) * NB * NB) for _ in range(2 if self.lookahead else 1)] \
             if self.coll else [None, None]
+        offs, starts = [], []
+        for k in range(max(self.T - 1, 0)):
+            cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
+            ck = max(cnts)
+            starts.append(len(offs))
+            for b in range(k + 1, self.T):
+                r = b % G
+                first = r + self._lstart(k, r) * G
+                offs.append((r * ck + (b - first) // G) * NB * NB)
+        self.boff_h = np.ascontiguousarray(offs or [0], dtype=np.int64)
+        self.boff = torch.from_numpy(self.boff_h).to(self.dev)
+        self.boff_start = starts
         self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         self.red = self._tensor(max(self.nloc, 1) + 1, 2)
         self.m = self._tensor(self.Np)
@@ -317,9 +344,47 @@ class DistGP:
             side.wait_event(ev)
 
     # ------------------------------------------------------------------ fit
-    def _panel_step(self, k, P):
+    def _gather_panel(self, k, buf, r0):
+        """all-gather of block column k below the diagonal: this rank's solved rows (from local row r0) are
+        packed into the send buffer, every rank's chunk lands in buf at rank * cmax_k blocks; runs on the
+        current stream.  Consumers address the blocks through the offset table of step k."""
+        NB, G, A = self.NB, self.G, self.A
+        c0 = k * NB
+        cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
+        cmax = max(cnts)
+        cnt = cnts[self.rank]
+        if cnt:
+            self.send[:cnt * NB * NB].view(cnt * NB, NB).copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
+        dist.all_gather_into_tensor(buf[:G * cmax * NB * NB], self.send[:cmax * NB * NB], group=self.group)
+
+    def _pblock(self, k, buf, i):
+        """block k + 1 + i of panel column k as an NB x NB tensor"""
+        NB = self.NB
+        if not self.coll:
+            r0 = (self._lstart(k) + i) * NB
+            return self.A[r0:r0 + NB, k * NB:(k + 1) * NB]
+        off = int(self.boff_h[self.boff_start[k] + i])
+        return buf[off:off + NB * NB].view(NB, NB)
+
+    def _update(self, k, buf, Cm, Am, first, rowmap=None, rowmap_h=None):
+        """Cm -= Am * (panel column k from its block `first` on)^T, columns of Cm in natural block order"""
+        ops, NB = self.ops, self.NB
+        if not self.coll:
+            r0 = (self._lstart(k) + first) * NB
+            nrow = Cm.shape[1]
+            P = self.A[r0:r0 + nrow, k * NB:(k + 1) * NB]
+            if rowmap is None:
+                ops.gemm_nt(Cm, Am, P)
+            else:
+                ops.gemm_nt_rowmap(Cm, Am, P, rowmap, 128, rowmap_h)
+            return
+        s0 = self.boff_start[k] + first
+        nblk = Cm.shape[1] // NB
+        ops.gemm_nt_blocks(Cm, Am, buf, NB, self.boff[s0:s0 + nblk], NB, rowmap, 128, rowmap_h)
+
+    def _panel_step(self, k, buf):
         """Block column k: owner factors the diagonal block, broadcast, every rank solves its
-        rows below, all-gather of the panel column into P (natural block order)."""
+        rows below, all-gather of the panel column into buf."""
         ops, NB, G, A = self.ops, self.NB, self.G, self.A
         owner = k % G
         c0 = k * NB
@@ -337,42 +402,7 @@ class DistGP:
             ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
         if k == self.T - 1 or not self.coll:
             return
-        cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
-        cmax = max(cnts)
-        cnt = cnts[self.rank]
-        nbelow = self.T - k - 1
-        send = self.send[:cmax * NB]
-        if cnt:
-            send[:cnt * NB].copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
-        recv = self.recv[:G * cmax * NB]
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        Pv = P[:nbelow * NB].view(nbelow, NB, NB)
-        R = recv.view(G, cmax, NB, NB)
-        for r in range(G):
-            if cnts[r]:
-                first = r + self._lstart(k, r) * G        # global index of r's first block below k
-                Pv[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
-
-    def _gather_panel(self, k, P, r0):
-        """all-gather of block column k below the diagonal (every rank's solved rows, starting at local
-        row r0) into P in natural block order; runs on the current stream"""
-        NB, G, A = self.NB, self.G, self.A
-        c0 = k * NB
-        cnts = [self._nblocks(r) - self._lstart(k, r) for r in range(G)]
-        cmax = max(cnts)
-        cnt = cnts[self.rank]
-        nbelow = self.T - k - 1
-        send = self.send[:cmax * NB]
-        if cnt:
-            send[:cnt * NB].copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
-        recv = self.recv[:G * cmax * NB]
-        dist.all_gather_into_tensor(recv, send, group=self.group)
-        Pv = P[:nbelow * NB].view(nbelow, NB, NB)
-        R = recv.view(G, cmax, NB, NB)
-        for r in range(G):
-            if cnts[r]:
-                first = r + self._lstart(k, r) * G
-                Pv[first - k - 1::G][:cnts[r]].copy_(R[r, :cnts[r]])
+        self._gather_panel(k, buf, r0)
 
     def _factor_critical_path_first(self):
         """Right-looking sweep with the diagonal chain decoupled from the panel chain.
@@ -397,12 +427,17 @@ class DistGP:
             if self.coll:
                 dist.broadcast(Lk[0], src=self._src(0), group=self.group)
         ev_bcast = self._record("crit")
+        ev_panel_prev = None                             # side-stream work of step k-1 (last reader of Lk[(k+1) % 2])
         for k in range(T):
             Lcur = Lk[k % 2]
+            buf = self.Pbuf[k % 2]
             c0, c1 = k * NB, (k + 1) * NB
             ls = self._lstart(k)                         # my first local block below k
             own_next = (k + 1 < T) and (self.rank == (k + 1) % G)
             ev_row = None
+            # Lk[(k+1) % 2] is overwritten below (owner: copy of its new diagonal block; everyone: the
+            # broadcast); its last reader is the side stream's solve of step k-1
+            self._wait("crit", ev_panel_prev)
             if own_next:                                 # block k+1 is my local block `ls`
                 self._wait("crit", ev_a)                 # its columns <= k+1 are final up to step k-1
                 with self._on("crit"):
@@ -422,8 +457,9 @@ class DistGP:
                     ops.trsm_block(Lcur, A[r_rest:r_rest + m, c0:c0 + NB])
                 if k < T - 1 and self.coll:
                     self._wait("side", ev_row)
-                    self._gather_panel(k, self.Pbuf[k % 2], ls * NB)
+                    self._gather_panel(k, buf, ls * NB)
             ev_panel = self._record("side")
+            ev_panel_prev = ev_panel
             if k == T - 1:
                 self._wait("main", ev_panel)
                 break
@@ -434,31 +470,22 @@ class DistGP:
             self._wait("main", ev_panel)
             if not self.coll:
                 self._wait("main", ev_row)
-            P = self._panel_view(k, self.Pbuf[k % 2])
             r1 = self._lstart(k + 1) * NB                # my rows of blocks > k+1 (and the y rows)
             m1 = self.rows - r1
             if m1 > 0:                                   # (a) block column k+1 below its diagonal block
-                ops.gemm_nt(A[r1:r1 + m1, c1:c1 + NB], A[r1:r1 + m1, c0:c0 + NB], P[:NB])
+                ops.gemm_nt(A[r1:r1 + m1, c1:c1 + NB], A[r1:r1 + m1, c0:c0 + NB], self._pblock(k, buf, 0))
             ls1 = self._lstart(k + 1)
             if k + 2 < T and ls1 < self.nloc and self.my_blocks[ls1] == k + 2:
                 # (a2) the diagonal block of my block row k+2: everything the next critical step reads
                 rows = slice(ls1 * NB, (ls1 + 1) * NB)
-                ops.gemm_nt(A[rows, c1 + NB:c1 + 2 * NB], A[rows, c0:c0 + NB], P[NB:2 * NB])
+                ops.gemm_nt(A[rows, c1 + NB:c1 + 2 * NB], A[rows, c0:c0 + NB], self._pblock(k, buf, 1))
             ev_a = self._record("main")
             if k + 2 < T and m1 > 0:                     # (b) the remaining columns
                 off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
-                ops.gemm_nt_rowmap(A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], P[NB:],
-                                   self.rowmapC[off:off + ln], 128, self.rowmapC_h[off:off + ln])
+                self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
+                             self.rowmapC[off:off + ln], self.rowmapC_h[off:off + ln])
         self._wait("main", ev_bcast)
         self._wait("main", self._record("crit"))
-
-    def _panel_view(self, k, P):
-        """the panel column below block k in natural order (blocks k+1 ..)"""
-        nbelow = self.T - k - 1
-        if not self.coll:
-            r0 = self._lstart(k) * self.NB
-            return self.A[r0:r0 + nbelow * self.NB, k * self.NB:(k + 1) * self.NB]
-        return P[:nbelow * self.NB]
 
     def factorize(self, sigma, ell, noise_var):
         """K + sI -> L (distributed), m = L^-1 y; returns the log-marginal-likelihood
@@ -495,21 +522,20 @@ class DistGP:
                 m = self.rows - r0
                 if m > 0:
                     off, ln = self.rowmap_off[k], self.rowmap_len[k]
-                    ops.gemm_nt_rowmap(A[r0:r0 + m, (k + 1) * NB:self.Np], A[r0:r0 + m, k * NB:(k + 1) * NB],
-                                       self._panel_view(k, self.Pbuf[0]), self.rowmap[off:off + ln], 128,
-                                       self.rowmap_h[off:off + ln])
+                    self._update(k, self.Pbuf[0], A[r0:r0 + m, (k + 1) * NB:self.Np], A[r0:r0 + m, k * NB:(k + 1) * NB], 0,
+                                 self.rowmap[off:off + ln], self.rowmap_h[off:off + ln])
         else:
             self._order(first_is_side=False)              # side waits for the K build
             with self._side():
                 self._panel_step(0, self.Pbuf[0])
             for k in range(T - 1):
                 self._order(first_is_side=True)           # main waits for panel k
-                P = self._panel_view(k, self.Pbuf[k % 2])
+                buf = self.Pbuf[k % 2]
                 c0, c1 = k * NB, (k + 1) * NB
                 r0 = self._lstart(k) * NB                 # my rows of blocks > k (and the y rows)
                 m = self.rows - r0
                 if m > 0:                                 # (a) block column k+1
-                    ops.gemm_nt(A[r0:r0 + m, c1:c1 + NB], A[r0:r0 + m, c0:c0 + NB], P[:NB])
+                    ops.gemm_nt(A[r0:r0 + m, c1:c1 + NB], A[r0:r0 + m, c0:c0 + NB], self._pblock(k, buf, 0))
                 self._order(first_is_side=False)          # side waits for (a)
                 with self._side():
                     self._panel_step(k + 1, self.Pbuf[(k + 1) % 2])
@@ -518,8 +544,8 @@ class DistGP:
                     m1 = self.rows - r1
                     if m1 > 0:
                         off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
-                        ops.gemm_nt_rowmap(A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], P[NB:],
-                                           self.rowmapB[off:off + ln], 128, self.rowmapB_h[off:off + ln])
+                        self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
+                                     self.rowmapB[off:off + ln], self.rowmapB_h[off:off + ln])
             self._order(first_is_side=True)               # main waits for the last panel
         # not-PD: smallest failing global column over all ranks
         if self.coll:

@@ -243,6 +243,15 @@ int gpmi_dev_gemm_nt_rowmap_host(void* stream, double* C_dev, int64_t ldc, const
                                  const double* B_dev, int64_t ldb, int64_t M, int64_t N, int64_t K,
                                  const int32_t* row_ncols_dev, const int32_t* row_ncols_host, int64_t row_bands,
                                  int64_t row_block_rows);
+/* C (M x N) -= A (M x K) * B^T with B given as a TABLE of row blocks: block i (b_block_rows x K, leading dimension
+ * ldb) starts at B_dev + b_block_off_dev[i] doubles (device array, ceil(N / b_block_rows) entries).  The
+ * multi-rank driver reads the panel column this way straight from the all-gather's receive buffer (one
+ * contiguous chunk per rank) in natural block order -- no re-ordering copy.  The row map is optional
+ * (row_ncols_dev and row_ncols_host both NULL: plain rectangle). */
+int gpmi_dev_gemm_nt_blocks(void* stream, double* C_dev, int64_t ldc, const double* A_dev, int64_t lda,
+                            const double* B_dev, int64_t ldb, const int64_t* b_block_off_dev, int64_t b_block_rows,
+                            int64_t M, int64_t N, int64_t K, const int32_t* row_ncols_dev,
+                            const int32_t* row_ncols_host, int64_t row_bands, int64_t row_block_rows);
 /* out2[0] = sum_{i<n} log(A[i][i]) (skipped if A_dev is NULL), out2[1] = sum_{i<nx} x[i]^2
  * (skipped if x_dev is NULL): the per-rank pieces of the log-marginal-likelihood */
 int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,

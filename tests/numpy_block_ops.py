@@ -81,6 +81,20 @@ class NumpyBlockOps:
             w_t = min((w + 127) // 128 * 128, c.shape[1])     # the kernel works on whole 128-col tiles
             c[rs, :w_t] -= a[rs] @ b[:w_t].T
 
+    def gemm_nt_blocks(self, Cm, A, Bflat, ldb, boff, brows, row_ncols=None, row_block_rows=128, row_ncols_host=None):
+        c, a = self._a(Cm), self._a(A)
+        flat, K = self._a(Bflat), a.shape[1]
+        nblk = c.shape[1] // brows
+        b = np.vstack([flat[int(o):int(o) + brows * ldb].reshape(brows, ldb)[:, :K] for o in boff.numpy()[:nblk]])
+        if row_ncols is None:
+            c -= a @ b.T
+            return
+        nc = row_ncols.numpy()
+        for q in range(c.shape[0] // row_block_rows):
+            rs = slice(q * row_block_rows, (q + 1) * row_block_rows)
+            w_t = min((int(nc[q]) + 127) // 128 * 128, c.shape[1])
+            c[rs, :w_t] -= a[rs] @ b[:w_t].T
+
     def logdiag_sumsq(self, A, n, x, nx, out2):
         o = self._a(out2)
         o[0] = np.log(np.diagonal(self._a(A))[:n]).sum() if A is not None else 0.0

@@ -151,6 +151,49 @@ def test_row_map_update_live_supertiles_only(M, N, K, band_rows):
     assert np.allclose(outs[1], want, rtol=0, atol=1e-10 * np.abs(want).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,brows,with_map", [(1024, 2048, 256, 256, True), (2560, 3072, 512, 512, True),
+                                                  (512, 1024, 128, 128, False), (384, 768, 1024, 128, True)])
+def test_block_table_update_reads_the_gather_buffer_in_natural_order(M, N, K, brows, with_map):
+    """gpmi_dev_gemm_nt_blocks: B scattered as row blocks in a flat buffer (the all-gather's receive buffer: one chunk
+    per rank) read through an offset table == the same update on the assembled B, bit for bit."""
+    import torch
+    from gaussian_process_amd.dist import HipBlockOps
+    ops = HipBlockOps(0)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(M + N + K)
+    nblk = N // brows
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((N, K))
+    C0 = rng.standard_normal((M, N))
+    perm = rng.permutation(nblk + 3)[:nblk]                      # where each natural block sits in the flat buffer
+    flat = np.full(((nblk + 3) * brows, K), np.nan)
+    for i, q in enumerate(perm):
+        flat[q * brows:(q + 1) * brows] = B[i * brows:(i + 1) * brows]
+    boff = torch.from_numpy((perm * brows * K).astype(np.int64)).to(dev)
+    reach_h = rm = None
+    if with_map:
+        bands = M // 128
+        reach_h = np.minimum(N, 256 + 3 * 128 * np.arange(bands)).astype(np.int32)
+        reach_h[-1] = N
+        rm = torch.from_numpy(reach_h).to(dev)
+    Ad, Bd, Fd = torch.from_numpy(A).to(dev), torch.from_numpy(B).to(dev), torch.from_numpy(flat.reshape(-1)).to(dev)
+    C1 = torch.from_numpy(C0).to(dev)
+    ops.gemm_nt_blocks(C1, Ad, Fd, K, boff, brows, rm, 128, reach_h)
+    C2 = torch.from_numpy(C0).to(dev)
+    if with_map:
+        ops.gemm_nt_rowmap(C2, Ad, Bd, rm, 128, reach_h)
+    else:
+        ops.gemm_nt(C2, Ad, Bd)
+    torch.cuda.synchronize()
+    got, ref = C1.cpu().numpy(), C2.cpu().numpy()
+    assert np.all(np.isfinite(got))
+    if M // 128 * (N // 128) >= 256:
+        assert np.array_equal(got, ref)                           # same kernel, same tiles: identical bits
+    else:
+        assert np.allclose(got, ref, rtol=0, atol=1e-11 * np.abs(ref).max())   # the plain launch takes the small-tile kernel
+
+
 def _bench(args, env_extra, timeout=900):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
