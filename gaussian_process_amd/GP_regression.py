@@ -70,8 +70,19 @@ def _select_kernel(ctx, kernel_choice, parameter, sigma):
     raise ValueError("kernel_choice must be 'rbf', 'lin' or 'per', got %r" % (kernel_choice,))
 
 
+def _dist_of(n_gpus, dist):
+    """n_gpus / dist keywords: None -> single-GPU context; a DistGP -> that; n_gpus > 1 -> the
+    process-wide DistGP over WORLD (every rank must make the same call)."""
+    if dist is not None:
+        return dist
+    if n_gpus is not None and int(n_gpus) > 1:
+        from .dist import default_dist
+        return default_dist(n_gpus)
+    return None
+
+
 def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIGMA_F,
-               noise_var=NOISE_VAR, jitter=POST_JITTER, return_lml=False, ctx=None):
+               noise_var=NOISE_VAR, jitter=POST_JITTER, return_lml=False, ctx=None, n_gpus=None, dist=None):
     """GP posterior at the test points, reference GP_regression.py:109-156.
 
     :return: (mu_post (n,), stand_devi (n,), f_post_fun (n, num_fun)); with return_lml=True a
@@ -81,6 +92,21 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
     would (K + sI at :138, posterior covariance at :154).  The normals of :155
     are drawn on the host from np.random in the reference's order.
     """
+    gp = _dist_of(n_gpus, dist)
+    if gp is not None:
+        # the covariance row-block partitioned over the ranks of the node (dist.py); every rank makes this call
+        # with the same arguments and gets the same results; the normals of :155 come from each rank's own
+        # np.random (seed them alike for identical samples)
+        if kernel_choice != 'rbf':
+            raise ValueError("the multi-GPU path covers the squared-exponential kernel (kernel_choice='rbf')")
+        from ._lib import scalar
+        lml = gp.fit(X_train, y_train, sigma, scalar(l, "l"), noise_var)
+        mu_post, stand_devi = gp.predict(X_test, want_sd=True)
+        L_ = gp.post_chol(jitter)
+        f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(mu_post.shape[0], num_fun)))
+        if return_lml:
+            return mu_post, stand_devi, f_post_fun, np.float64(lml)
+        return mu_post, stand_devi, f_post_fun
     ctx = ctx or default_context()
     try:
         sg, ll = _select_kernel(ctx, kernel_choice, l, sigma)  # :125-136

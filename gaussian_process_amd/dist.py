@@ -502,6 +502,7 @@ class DistGP:
         ops, NB, G, A = self.ops, self.NB, self.G, self.A
         self.sigma, self.ell = float(sigma), float(ell)
         self.have_factor = False
+        self.have_v = False
         self.info.fill_(INT64_MAX)
         # K + sI: my row blocks, lower part
         for li, b in enumerate(self.my_blocks):
@@ -594,6 +595,7 @@ class DistGP:
         self.dots = self._tensor(2, self.n_p)
         self.m_loc = self._tensor(max(self.nloc, 1) * self.NB)
         self.have_test = True
+        self.have_v = False
 
     def predict_resident(self, want_sd=True):
         """mu = K_s^T alpha (as v^T m), var = sigma^2 - sum(v^2) (GP_regression.py:143-148)."""
@@ -668,6 +670,7 @@ class DistGP:
             mu += alld[r, 0]
             sq += alld[r, 1]
         var = self.sigma ** 2 - sq[:self.n]
+        self.have_v = True
         self.stage_ms["predict"] = (time.perf_counter() - t_begin) * 1e3
         with np.errstate(invalid="ignore"):
             out2 = np.sqrt(var) if want_sd else var
@@ -676,6 +679,33 @@ class DistGP:
     def predict(self, Xs, want_sd=True):
         self.set_test(Xs)
         return self.predict_resident(want_sd)
+
+    # ------------------------------------------------------------------ posterior covariance factor (f1)
+    def post_chol(self, jitter):
+        """L_ = cholesky(K_ss + jitter * I - v^T v) (GP_regression.py:153-154) with v distributed: every rank forms
+        the contribution of its own column blocks of v^T (one MFMA SYRK), the contributions are summed by one
+        all-reduce of n_p x n_p doubles, and every rank factors the small matrix itself (same bits on every
+        rank).  Needs predict_resident() first.  Returns the n x n lower factor; raises LinAlgError if not PD."""
+        if not (self.have_factor and self.have_test and getattr(self, "have_v", False)):
+            raise ValueError("post_chol needs a factorisation and predict_resident() first")
+        ops, NB, n_p = self.ops, self.NB, self.n_p
+        P = self._tensor(n_p, n_p + self.ld_pad)
+        Gm = self._tensor(n_p, n_p + self.ld_pad)
+        Gm.zero_()
+        if self.nloc:
+            ops.gemm_nt(Gm[:, :n_p], self.V[:, :self.nloc * NB], self.V[:, :self.nloc * NB])     # Gm = -v_loc^T v_loc
+        if self.coll:
+            dist.all_reduce(Gm, op=dist.ReduceOp.SUM, group=self.group)
+        ops.rbf_rows(self.Xs, self.n, self.d, 0, n_p, n_p, self.sigma, self.ell, float(jitter), P)
+        P[:, :n_p].add_(Gm[:, :n_p])
+        info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
+        ops.potrf_block(P[:, :n_p], 0, info)
+        bad = int(info.item())
+        if bad != INT64_MAX and bad < self.n:
+            err = np.linalg.LinAlgError("Matrix is not positive definite")
+            err.bad_pivot = bad + 1
+            raise err
+        return np.tril(P[:self.n, :self.n].cpu().numpy())
 
     # ------------------------------------------------------------------ alpha
     def alpha(self):
@@ -739,6 +769,28 @@ class DistGP:
 
     def timers(self):
         return dict(self.stage_ms)
+
+
+_default = {}
+
+
+def default_dist(n_gpus=None):
+    """The DistGP over WORLD that the drop-in functions use for `n_gpus=`: one per process,
+    created on first use on this rank's device.  torch.distributed must already be initialised by the launcher
+    (one process per GPU); n_gpus, when given, must be the world size."""
+    if not dist.is_initialized():
+        raise RuntimeError("n_gpus needs torch.distributed initialised by the launcher (one process per GPU, e.g. "
+                           "python -m torch.distributed.run --nproc-per-node N ...)")
+    world = dist.get_world_size()
+    if n_gpus is not None and int(n_gpus) != world:
+        raise ValueError("n_gpus=%s but the process group has %d ranks" % (n_gpus, world))
+    gp = _default.get("gp")
+    if gp is None:
+        import os
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        nb = int(os.environ.get("GPMI_DIST_NB", "512"))
+        gp = _default["gp"] = DistGP(dev, nb=nb)
+    return gp
 
 
 def sharded_lml_batch(triples, evaluate, group=None):

@@ -14,9 +14,16 @@ NOISE_VAR = 0.0005      # tune_hyperparms_regression.py:302
 BO_NOISE_VAR = 0.0001   # tune_hyperparms_regression.py:75
 
 
-def compute_mar_likelihood(X_train, X_test, y_train, sigma, l, *, noise_var=NOISE_VAR, ctx=None):
+def compute_mar_likelihood(X_train, X_test, y_train, sigma, l, *, noise_var=NOISE_VAR, ctx=None, n_gpus=None,
+                           dist=None):
     """Log marginal likelihood, reference tune_hyperparms_regression.py:292-313.
-    X_test is accepted and unused, exactly as in the reference."""
+    X_test is accepted and unused, exactly as in the reference.  n_gpus / dist: factorise with the covariance
+    row-block partitioned over the ranks of the node (every rank makes the same call)."""
+    from .GP_regression import _dist_of
+    gp = _dist_of(n_gpus, dist)
+    if gp is not None:
+        from ._lib import scalar
+        return np.float64(gp.fit(X_train, y_train, scalar(sigma, "sigma"), scalar(l, "l"), noise_var))
     ctx = ctx or default_context()
     return np.float64(ctx.fit(X_train, y_train, sigma, l, noise_var))
 

@@ -30,6 +30,14 @@ def main():
     lml = gp.fit(X, y, 1.0, 2.0 * np.sqrt(d / 8.0), 5e-4)
     mu, var = gp.predict(Xs, want_sd=False)
     alpha = gp.alpha()
+    Lp = gp.post_chol(1e-6)                                       # f1 distributed (GP_regression.py:153-154)
+    # the drop-in surface routed to the multi-rank driver (additive dist= / n_gpus= keywords)
+    from gaussian_process_amd import GP_regression as G
+    from gaussian_process_amd import tune_hyperparms_regression as T
+    np.random.seed(123)
+    d_mu, d_sd, d_fp, d_lml = G.prediction(X, Xs, y, 'rbf', 2.0 * np.sqrt(d / 8.0), 2, return_lml=True, dist=gp)
+    d_cml = T.compute_mar_likelihood(X, None, y, 1, 2.0 * np.sqrt(d / 8.0), dist=gp)
+    gp.set_test(Xs)
     lml2 = gp.factorize(1.3, 1.5 * np.sqrt(d / 8.0), 1e-3)        # refit on resident data
     mu2, sd2 = gp.predict_resident(want_sd=True)
     raised = 0
@@ -56,7 +64,8 @@ def main():
         evaluate = ctx.lml_batch
     blml, bst = sharded_lml_batch(triples, evaluate)
     np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised,
-             blml=blml, bst=bst, triples=triples, alpha=alpha)
+             blml=blml, bst=bst, triples=triples, alpha=alpha, Lp=Lp, d_mu=d_mu, d_sd=d_sd, d_fp=d_fp, d_lml=d_lml,
+             d_cml=d_cml)
     dist.barrier()
     dist.destroy_process_group()
 

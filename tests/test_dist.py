@@ -44,7 +44,18 @@ def _check(res, oracle, N, d, n):
     kbad = next(i for i in range(1, N + 1) if np.linalg.eigvalsh(K[:i, :i]).min() <= 0)
     want_batch = [None if s2 < 0 else oracle.fit_predict_feasible(X, Xs[:1], y, sf, l, s2, use_c=False)["lml"]
                   for (l, sf, s2) in res[0]["triples"]]
+    # f1 distributed: the posterior-covariance factor and the drop-in prediction(..., dist=gp)
+    pref = oracle.posterior(X, Xs, y, 1.0, ell, 5e-4) if N <= 1200 else None
+    if pref is not None:
+        Lref = np.linalg.cholesky(pref["K_ss"] + 1e-6 * np.eye(n) - pref["v"].T @ pref["v"])
+        np.random.seed(123)
+        fref = pref["mu"].reshape(-1, 1) + Lref @ np.random.normal(size=(n, 2))
     for r in res:
+        if pref is not None:
+            assert np.max(np.abs(r["Lp"] - Lref)) <= 1e-6
+            assert np.max(np.abs(r["d_fp"] - fref)) <= 1e-6
+        assert np.max(np.abs(r["d_mu"] - ref["mu"])) <= 1e-9 and abs(r["d_lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
+        assert r["d_cml"] == r["d_lml"]
         assert abs(r["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
         assert np.max(np.abs(r["mu"] - ref["mu"])) <= 1e-9
         assert np.max(np.abs(r["var"] - ref["var"])) <= 1e-10
@@ -61,7 +72,7 @@ def _check(res, oracle, N, d, n):
                 want = want_batch[t]
                 assert abs(r["blml"][t] - want) <= 1e-10 * abs(want) and r["bst"][t] == 0
     for r in res[1:]:                      # every rank returns the same bits
-        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml", "alpha"):
+        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml", "alpha", "Lp", "d_fp"):
             assert np.array_equal(r[key], res[0][key], equal_nan=True), key
 
 
