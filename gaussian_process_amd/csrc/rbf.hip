@@ -18,6 +18,8 @@
 // 1-KiB row segments (64 lanes x 16 B).  The x rows of both tile edges are
 // staged once in LDS; for the common d (1..8, 16) the b values of a thread's two
 // columns live in registers and the a values are wave-wide LDS broadcasts.
+#include <cmath>
+
 #include "gpmi_internal.h"
 
 namespace gpmi {
@@ -110,6 +112,45 @@ __device__ __forceinline__ void exp_pair(double x0, double x1, double& e0, doubl
     if (__builtin_amdgcn_ballot_w64(!ok) == 0) {                // compare mask straight into SGPRs
         e0 = exp_neg_fast(x0);
         e1 = exp_neg_fast(x1);
+    } else {
+        e0 = exp(x0);
+        e1 = exp(x1);
+    }
+}
+
+// exp(x) for x <= 0 with a 4096-entry table of 2^(j/4096) in LDS (32 KiB per workgroup, filled from a
+// device-resident copy at kernel start; the host computes the entries in extended precision).
+//   x = (4096 k + j) ln2 / 4096 + r,  |r| <= ln2 / 8192:   exp(x) = 2^k * T[j] * (1 + r + r^2/2 + r^3/6)
+// (the cubic's truncation error is r^4 / 24 < 2.2e-18 relative; a 2048-entry table leaves 0.3 ulp there).  13 vector instructions against the 17 of
+// the polynomial-only form above (the K build is bound by its instruction count):
+// one multiply-add for k and j at once, a two-term Cody-Waite reduction, two instructions each for the table
+// address and for the exponent, three for the cubic, one for T + T q.  T[0] == 1 and r == 0 at x == 0, so
+// exp(0) == 1 exactly and the diagonal of K stays sigma^2.  Error: 0.5 ulp of the table entry + 0.5 ulp of the
+// final fused multiply-add (measured: scripts/exp_accuracy.py).  Same domain as exp_neg_fast.
+constexpr int EXP_TAB = 4096;
+constexpr int EXP_TAB_LOG = 12;
+__device__ double g_exp2_tab[EXP_TAB];
+
+__device__ __forceinline__ double exp_neg_tab(double x, const double* __restrict__ tab) {
+    const double MAGIC = 6755399441055744.0 / (double)EXP_TAB;        // 1.5 * 2^52 / 4096: one unit in the last place = 1/4096
+    const double t = fma(x, 1.4426950408889634074, MAGIC);            // low word: round(4096 x log2 e) = 4096 k + j
+    const double n = t - MAGIC;                                       // (4096 k + j) / 4096
+    double r = fma(-n, 6.93147180369123816490e-01, x);                // ln2_hi (trailing zero bits: exact product while |x| < 700)
+    r = fma(-n, 1.90821492927058770002e-10, r);                       // ln2_lo
+    const int m = __double2loint(t);
+    const double T = tab[m & (EXP_TAB - 1)];
+    double q = fma(r, 1.0 / 6.0, 0.5);
+    q = fma(q, r, 1.0);
+    q = q * r;                                                        // r + r^2/2 + r^3/6
+    const double e = fma(T, q, T);
+    return __hiloint2double((int)(((unsigned)(m & ~(EXP_TAB - 1)) << (20 - EXP_TAB_LOG)) + (unsigned)__double2hiint(e)), __double2loint(e));
+}
+
+__device__ __forceinline__ void exp_pair_tab(double x0, double x1, double& e0, double& e1, const double* tab) {
+    const bool ok = (x0 >= -700.0) & (x1 >= -700.0);
+    if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
+        e0 = exp_neg_tab(x0, tab);
+        e1 = exp_neg_tab(x1, tab);
     } else {
         e0 = exp(x0);
         e1 = exp(x1);
@@ -279,7 +320,7 @@ __device__ __forceinline__ void rbf_load_cols(const RbfDev& p, const double* __r
 template <int D, bool EDGE, bool CHECK = true, bool UNIT = false>
 __device__ __forceinline__ void rbf_tile_rows(const RbfDev& p, const double* __restrict__ Ap,
                                               double* __restrict__ outp, int64_t grow0, int64_t gcol0, int ti,
-                                              const double (&b0)[D], const double (&b1)[D]) {
+                                              const double (&b0)[D], const double (&b1)[D], const double* tab) {
     const int cp = threadIdx.x & 63;
     const int rg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if constexpr (EDGE) {
@@ -294,7 +335,9 @@ __device__ __forceinline__ void rbf_tile_rows(const RbfDev& p, const double* __r
             for (int k = 0; k < D; ++k) av[k] = ar[k];               // scalar loads (uniform address)
             const double s0 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b0[k]; });
             const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
-            rbf_finish(p, gr, gc, s0, s1, out0 + (int64_t)r * p.ld);
+            double e0, e1;
+            exp_pair_tab(p.coef * s0, p.coef * s1, e0, e1, tab);
+            cov_store(p, gr, gc, p.sig2 * e0, p.sig2 * e1, out0 + (int64_t)r * p.ld);
         }
     } else {
         // wave-uniform row base + constant 32-bit lane offset: the store takes the scalar-base form
@@ -311,10 +354,10 @@ __device__ __forceinline__ void rbf_tile_rows(const RbfDev& p, const double* __r
             const double s1 = sq_pw_static<D>([&](int k) { return av[k]; }, [&](int k) { return b1[k]; });
             double e0, e1;
             if constexpr (CHECK) {
-                exp_pair(p.coef * s0, p.coef * s1, e0, e1);
+                exp_pair_tab(p.coef * s0, p.coef * s1, e0, e1, tab);
             } else {
-                e0 = exp_neg_fast(p.coef * s0);
-                e1 = exp_neg_fast(p.coef * s1);
+                e0 = exp_neg_tab(p.coef * s0, tab);
+                e1 = exp_neg_tab(p.coef * s1, tab);
             }
             if constexpr (!UNIT) { e0 = p.sig2 * e0; e1 = p.sig2 * e1; }   // sigma^2 == 1: the product is exact
             // global_store with SGPR base: the per-row address costs no vector instruction
@@ -330,6 +373,10 @@ __device__ __forceinline__ void rbf_tile_rows(const RbfDev& p, const double* __r
 template <int D>
 __global__ __launch_bounds__(256) void rbf_regs_kernel(const double* __restrict__ Ap, const double* __restrict__ Bp,
                                                         double* __restrict__ outp, const RbfDev p) {
+    __shared__ __attribute__((aligned(16))) double tab[EXP_TAB];
+    for (int i = 2 * threadIdx.x; i < EXP_TAB; i += 512)
+        *reinterpret_cast<d2*>(tab + i) = *reinterpret_cast<const d2*>(g_exp2_tab + i);
+    __syncthreads();
     const bool unit = p.sig2 == 1.0;
     const int row_tile0 = (int)(p.row0 / RT);
     for (int item = blockIdx.x; item < p.nitems; item += gridDim.x) {
@@ -351,14 +398,14 @@ __global__ __launch_bounds__(256) void rbf_regs_kernel(const double* __restrict_
                 // launch-uniform specialisations of the interior loop: no per-wave domain test when the
                 // host has bounded the arguments, no sigma^2 multiply when it is 1 (the reference's default)
                 if (p.nocheck) {
-                    if (unit) rbf_tile_rows<D, false, false, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
-                    else rbf_tile_rows<D, false, false, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                    if (unit) rbf_tile_rows<D, false, false, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1, tab);
+                    else rbf_tile_rows<D, false, false, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1, tab);
                 } else {
-                    if (unit) rbf_tile_rows<D, false, true, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
-                    else rbf_tile_rows<D, false, true, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                    if (unit) rbf_tile_rows<D, false, true, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1, tab);
+                    else rbf_tile_rows<D, false, true, false>(p, Ap, outp, grow0, gcol0, ti, b0, b1, tab);
                 }
             } else {
-                rbf_tile_rows<D, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1);
+                rbf_tile_rows<D, true>(p, Ap, outp, grow0, gcol0, ti, b0, b1, tab);
             }
         }
     }
@@ -437,6 +484,16 @@ __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
     }
 }
 
+// 2^(j/2048) rounded to double from an extended-precision evaluation, uploaded once per device
+static hipError_t exp_table_ready() {
+    static PerDeviceOnce once;
+    return once.run([]() -> hipError_t {
+        static double h[EXP_TAB];
+        for (int j = 0; j < EXP_TAB; ++j) h[j] = (double)exp2l((long double)j / (long double)EXP_TAB);
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_exp2_tab), h, sizeof h, 0, hipMemcpyHostToDevice);
+    });
+}
+
 hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     if (a.nrows <= 0 || a.ncols <= 0) return hipSuccess;
     if (a.nrows % RT || a.ncols % RT || a.d <= 0) return hipErrorInvalidValue;
@@ -459,6 +516,10 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     if (a.kind != 0) {
         hipLaunchKernelGGL(cov_other_kernel, grid, block, 0, s, p);
         return hipGetLastError();
+    }
+    {
+        const hipError_t et = exp_table_ready();
+        if (et != hipSuccess) return et;
     }
     // big builds: 4 row tiles per block (b columns loaded once, 4x fewer block launches)
     p.strip = (nblk >= 4096) ? 4 : 1;
