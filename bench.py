@@ -353,13 +353,18 @@ def main():
                 out["alpha_hbm"] = {"bound": "hbm", "achieved": abytes / (al * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
                                     "unit": "GB/s", "frac": abytes / (al * 1e-3) / 1e9 / PEAK_HBM_GBPS, "bytes": abytes,
                                     "ms": al, "note": "a5: backward solve L^T alpha = m reads the triangle once"}
-            # what this box sustains on bare probe kernels (nominal peaks above are what fractions are priced against)
+            # the peaks as this box reports them (hipDeviceProp_t), next to the nominal ones the fractions are priced against
             try:
-                tf_probe, ghz, _ = ctx.probe_mfma_f64_ex(2, 16, 2048)
-                out["peaks_probe"] = {"fp64_mfma_tflops": tf_probe, "shader_clock_ghz": ghz,
-                                      "hbm_write_gbps": ctx.probe_hbm_write(1 << 30)}
-            except Exception as e:      # a probe must never cost the bench line
-                out["peaks_probe"] = {"error": str(e)}
+                di = ctx.device_info()
+                out["peaks_box"] = {
+                    "compute_units": di["compute_units"], "clock_khz": di["clock_khz"], "mem_clock_khz": di["mem_clock_khz"],
+                    "mem_bus_bits": di["mem_bus_bits"], "global_mem_gb": di["global_mem_bytes"] / 1e9,
+                    "fp64_mfma_tflops": di["compute_units"] * 4 * 32 * di["clock_khz"] * 1e3 / 1e12,
+                    "hbm_gbps": 2.0 * di["mem_clock_khz"] * 1e3 * di["mem_bus_bits"] / 8 / 1e9,
+                    "note": "fp64 matrix: CUs x 4 SIMDs x 32 flop/clk (one v_mfma_f64_16x16x4 = 2048 flop per 64 cycles) x "
+                            "clock; HBM: 2 x memory clock x bus width / 8; as reported by hipDeviceProp_t, not measured"}
+            except Exception as e:      # never cost the bench line
+                out["peaks_box"] = {"error": str(e)}
         out["targets"] = targets
         if world == 1 and not args.no_cpu_baseline and not force_dist:
             out["cpu_baseline"] = cpu_baseline(d, n)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "gpmi_probe_gemm": [_vp, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _dp],
     "gpmi_probe_hbm_write": [_vp, _i64, _dp],
     "gpmi_probe_hbm_ex": [_vp, _i64, C.c_int, C.c_int, _dp],
+    "gpmi_device_info": [_vp, _dp, C.c_int],
     "gpmi_probe_panel": [_vp, C.c_int, _i64, C.c_int, _dp, C.POINTER(C.c_uint64)],
     "gpmi_dev_rbf_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, C.c_double, _vp, _i64],
     "gpmi_dev_rbf_cross": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _vp, _i64],

@@ -327,6 +327,135 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
     gemm_nt_dma_body<2, false>(p);
 }
 
+// ---------------------------------------------------------------------------
+// Small launches (panel-internal updates, diagonal blocks, small problems: fewer 64 x 64 tiles than the chip has
+// room for): what they cost is the memory latency of every K step, not arithmetic -- the first-generation kernel
+// took ~2 us per K step of 16 because only one step was in flight.  Same LDS image and fragment maps as above,
+// 64 x 64 tiles, 4 waves of 32 x 32, and a ring of EIGHT stages filled by LDS-DMA before the first MFMA issues:
+// K = 128 is one memory round trip, deeper K keeps seven steps in flight.  One barrier per K step: it publishes
+// step c (every wave has waited for its own pieces) and frees the stage of step c - 1 for step c + 7.
+// ---------------------------------------------------------------------------
+constexpr int SM_T = 64;                                   // tile edge
+constexpr int SM_STAGES = 8;
+constexpr int SM_STAGE_SLOTS = (SM_T + SM_T) * 8;          // 16-byte slots per stage (A then B): 16 KiB
+
+struct GemmSmallDev {
+    double* C;
+    const double* A;
+    const double* B;
+    int64_t ldc, lda, ldb;
+    int Tm, Tn, nchunks;
+    int lower;
+    int64_t diag_off;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmSmallDev p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int ti = blockIdx.x / p.Tn, tj = blockIdx.x - ti * p.Tn;
+    if (p.lower) {
+        const int64_t min_col = (int64_t)tj * SM_T, max_row = (int64_t)ti * SM_T + SM_T - 1;
+        if (min_col > max_row + p.diag_off) return;
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;
+    const int fr = lane & 15, fg = lane >> 4;
+    // DMA: wave w moves rows 16 w .. 16 w + 15 of the A tile and of the B tile, 8 rows per instruction
+    const int drow = lane >> 3;
+    const int dkp = (lane & 7) ^ (drow & 7);
+    const double* a_src = p.A + ((int64_t)ti * SM_T + 16 * wave + drow) * p.lda + dkp * 2;
+    const double* b_src = p.B + ((int64_t)tj * SM_T + 16 * wave + drow) * p.ldb + dkp * 2;
+    GPMI_LDS char* lds = (GPMI_LDS char*)smem_raw;
+    auto issue = [&](int chunk) {
+        GPMI_LDS char* base = lds + (chunk % SM_STAGES) * (SM_STAGE_SLOTS * 16);
+        const int k0 = chunk * 16;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(a_src + (int64_t)(8 * q) * p.lda + k0),
+                                             (GPMI_LDS void*)(base + (16 * wave + 8 * q) * 128), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(b_src + (int64_t)(8 * q) * p.ldb + k0),
+                                             (GPMI_LDS void*)(base + SM_T * 128 + (16 * wave + 8 * q) * 128), 16, 0, 0);
+        }
+    };
+    const int nch = p.nchunks;
+    for (int c = 0; c < SM_STAGES && c < nch; ++c) issue(c);
+
+    const int x7 = fr & 7;
+    const int sl0 = fr * 8 + (fg ^ x7), sl1 = fr * 8 + ((4 + fg) ^ x7);
+    const d2* smem = reinterpret_cast<const d2*>(smem_raw);
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = d4{0., 0., 0., 0.};
+
+    for (int c = 0; c < nch; ++c) {
+        // pieces of steps c + 1 .. may still fly: 4 per step in flight behind step c (at most 7 steps)
+        const int behind = min(nch - 1 - c, SM_STAGES - 1 - (c > 0 ? 1 : 0));
+        // s_waitcnt takes an immediate: the steady state (28 or 24 pieces behind) and the drain
+        if (behind >= 7) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        else if (behind == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c > 0 && c - 1 + SM_STAGES < nch) issue(c - 1 + SM_STAGES);      // the stage step c - 1 has just left
+        const d2* sa = smem + (c % SM_STAGES) * SM_STAGE_SLOTS;
+        const d2* sb = sa + SM_T * 8;
+        d2 fa0[2], fa1[2], fb0[2], fb1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            fa0[i] = sa[(wr + 16 * i) * 8 + sl0];
+            fa1[i] = sa[(wr + 16 * i) * 8 + sl1];
+            fb0[i] = sb[(wc + 16 * i) * 8 + sl0];
+            fb1[i] = sb[(wc + 16 * i) * 8 + sl1];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[i].x, fb0[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa0[i].y, fb0[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[i].x, fb1[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa1[i].y, fb1[j].y, acc[i][j], 0, 0, 0);
+            }
+    }
+    // C -= acc: all loads of the tile first, then the stores
+    double* Cg = p.C + ((int64_t)ti * SM_T + wr) * p.ldc + (int64_t)tj * SM_T + wc;
+    auto c_ptr = [&](int i, int j, int v) { return Cg + (int64_t)(16 * i + 4 * v + fg) * p.ldc + 16 * j + fr; };
+    double cv[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cv[i][j][v] = *c_ptr(i, j, v);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) *c_ptr(i, j, v) = cv[i][j][v] - acc[i][j][v];
+}
+
+bool gemm_small_eligible(const GemmArgs& a) {
+    return a.mode == 0 && a.M % SM_T == 0 && a.N % SM_T == 0 && a.K % 16 == 0 && a.K >= 16 && !a.row_ncols && !a.b_block_off;
+}
+
+hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a) {
+    GemmSmallDev p;
+    p.C = a.C; p.A = a.A; p.B = a.B; p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
+    p.Tm = (int)(a.M / SM_T); p.Tn = (int)(a.N / SM_T); p.nchunks = (int)(a.K / 16);
+    p.lower = a.lower; p.diag_off = a.diag_off;
+    constexpr size_t lds = (size_t)SM_STAGES * SM_STAGE_SLOTS * 16;
+    static PerDeviceOnce once;
+    const hipError_t ea = once.run([&]() -> hipError_t {
+        return hipFuncSetAttribute((const void*)gemm_nt_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    });
+    if (ea != hipSuccess) return ea;
+    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((unsigned)(p.Tm * p.Tn)), dim3(256), lds, s, p);
+    return hipGetLastError();
+}
+
 bool gemm_dma_eligible(const GemmArgs& a) {
     return a.mode == 0 && a.N % 128 == 0 && a.M % 128 == 0 && a.K % 16 == 0 && a.K >= 32;
 }

@@ -283,6 +283,8 @@ hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
     // few tiles: one 128 x 128 tile keeps a CU busy for 1.8 us per 64 of K while the rest of the
     // chip idles -- 64 x 64 tiles finish 4x sooner (panel-internal updates, diagonal blocks)
     const int64_t tiles128 = (a.M / 128) * ((a.N + 127) / 128);
+    if (tn.gemm_small_tiles && tn.gemm_small_dma && !tn.gemm_dbg && tiles128 < 128 && gemm_small_eligible(a))
+        return launch_gemm_nt_small(s, a);
     if (tn.gemm_small_tiles && !tn.gemm_dbg && tiles128 < 128) {
         plan(a, 64, 64, p, nblocks);
         constexpr size_t lds = 2 * (KP * 64 + KP * 64) * 16;

@@ -104,6 +104,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->tune.gemm_small_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "trsm_wave")) {
         c->tune.trsm_wave = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_small_dma")) {
+        c->tune.gemm_small_dma = value ? 1 : 0;
     } else if (!strcmp(name, "panel_fused")) {
         c->tune.panel_fused = value ? 1 : 0;
     } else if (!strcmp(name, "rbf_blocks")) {

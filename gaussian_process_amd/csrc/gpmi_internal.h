@@ -22,6 +22,7 @@ struct Tuning {
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always
     int rbf_blocks = 16384;     // persistent blocks of the register-path K build
     int panel_fused = 1;        // 1: fused multi-column panel kernels, 0: first-generation potf2 + substitution leaves
+    int gemm_small_dma = 1;     // 1: deep-prefetch LDS-DMA kernel for launches with few tiles, 0: first-generation 64 x 64 kernel
     int gemm_dbg = 0;           // timing-only ablation bits (gpmi_probe_gemm); results are wrong when non-zero
     unsigned long long* gemm_stamps = nullptr;   // diagnostic stamp buffer (gpmi_probe_gemm variant bit 16)
     unsigned long long* panel_stamps = nullptr;  // diagnostic: s_memtime stamps of the panel kernels (gpmi_probe_panel)
@@ -85,6 +86,9 @@ double gemm_nt_algorithmic_flops(const GemmArgs& a, int64_t real_rows);   // 2K 
 // gemm_dma.hip: one-workgroup-per-CU LDS-DMA variant (mode 0, N % 128 == 0)
 bool gemm_dma_eligible(const GemmArgs& a);
 hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
+// gemm_dma.hip: latency-oriented variant for launches with few tiles (64 x 64 tiles, eight K steps in flight)
+bool gemm_small_eligible(const GemmArgs& a);
+hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a);
 // number of tiles the launch actually computes (for flop accounting)
 double gemm_nt_flops(const GemmArgs& a);
 

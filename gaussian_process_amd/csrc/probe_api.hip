@@ -141,6 +141,25 @@ int gpmi_probe_hbm_ex(gpmi_ctx* c, int64_t bytes, int mode, int blocks, double* 
     return GPMI_OK;
 }
 
+// What the device reports about itself (hipDeviceProp_t): out[0] compute units, out[1] shader clock (kHz),
+// out[2] memory clock (kHz), out[3] memory bus width (bits), out[4] total global memory (bytes), out[5] L2 (bytes),
+// out[6] LDS per workgroup (bytes), out[7] wavefront size.  bench.py derives the peaks it prices against from
+// these (fp64 matrix: CUs x 4 SIMDs x 32 flop/clk x clock; HBM: 2 x memory clock x bus width / 8).
+int gpmi_device_info(gpmi_ctx* c, double* out, int count) {
+    if (!c || !out || count < 8) return fail_arg("gpmi_device_info: need 8 output slots");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    out[0] = prop.multiProcessorCount;
+    out[1] = prop.clockRate;
+    out[2] = prop.memoryClockRate;
+    out[3] = prop.memoryBusWidth;
+    out[4] = (double)prop.totalGlobalMem;
+    out[5] = prop.l2CacheSize;
+    out[6] = (double)prop.sharedMemPerBlock;
+    out[7] = prop.warpSize;
+    return GPMI_OK;
+}
+
 // Panel kernels alone on scratch data: kind 0 potrf128 (one 128 x 128 block), kind 1 trsm128 on m rows.
 // out_us = median-free mean microseconds per launch over reps; stamps_out (64 entries, may be null) = the
 // s_memtime stamps of one further, instrumented launch (layout: panel_mfma.hip).

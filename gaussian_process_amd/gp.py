@@ -70,6 +70,14 @@ class GPContext:
         check(self._lib.gpmi_probe_gemm(self._h, M, N, K, lower, variant, reps, ptr(out)))
         return tuple(out)
 
+    def device_info(self):
+        """what hipDeviceProp_t reports: CUs, clocks (kHz), memory bus width (bits), memory sizes"""
+        out = np.zeros(8)
+        check(self._lib.gpmi_device_info(self._h, ptr(out), 8))
+        keys = ("compute_units", "clock_khz", "mem_clock_khz", "mem_bus_bits", "global_mem_bytes", "l2_bytes",
+                "lds_per_workgroup_bytes", "wavefront")
+        return {k: float(v) for k, v in zip(keys, out)}
+
     def probe_panel(self, kind, m=0, reps=20, stamps=False):
         """-> (microseconds per launch, stamps or None): potrf128 (kind 0) / trsm128 on m rows (kind 1) alone"""
         us = C.c_double()

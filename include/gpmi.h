@@ -194,6 +194,9 @@ int gpmi_probe_hbm_write(gpmi_ctx* ctx, int64_t bytes, double* gbps);
 /* streaming bandwidth with a chosen access form: mode 0 grid-stride 16-byte stores, 1 the same
  * non-temporal, 2 one contiguous span per workgroup, 3 span + non-temporal, 4 16-byte loads */
 int gpmi_probe_hbm_ex(gpmi_ctx* ctx, int64_t bytes, int mode, int blocks, double* gbps);
+/* what the device reports about itself: out[0] compute units, [1] shader clock kHz, [2] memory clock kHz,
+ * [3] memory bus width (bits), [4] global memory bytes, [5] L2 bytes, [6] LDS per workgroup bytes, [7] wavefront size */
+int gpmi_device_info(gpmi_ctx* ctx, double* out, int count);
 /* the panel kernels alone on scratch data: kind 0 = Cholesky of one 128 x 128 block (potrf128), kind 1 = X L^-T on
  * m rows (trsm128); *out_us = microseconds per launch; stamps_out (64 entries or NULL) = in-kernel clock stamps
  * of one instrumented launch (layout: csrc/panel_mfma.hip) */
