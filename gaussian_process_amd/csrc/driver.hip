@@ -135,6 +135,7 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     // below ~12k columns the two-stream choreography costs more than the panel it hides
     const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
     hipStream_t sp_ = la ? c->pstream : sm;
+    GemmShallowScope shallow(la);                 // panel-internal updates run beside the trailing update
     const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
     const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;   // panel 0 after the K build
@@ -278,6 +279,7 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri)
     const int64_t NB = c->block(Np);
     const bool la = c->lookahead && c->pstream && Np > NB && Np >= 12288;
     hipStream_t sp_ = la ? c->pstream : sm;
+    GemmShallowScope shallow(la);
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
     auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
         GemmArgs g;   // V[:, c0..c0+ncol_upd) -= V[:, k..k+nb) * L[c0.., k..k+nb)^T

@@ -335,9 +335,16 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
 // K = 128 is one memory round trip, deeper K keeps seven steps in flight.  One barrier per K step: it publishes
 // step c (every wave has waited for its own pieces) and frees the stage of step c - 1 for step c + 7.
 // ---------------------------------------------------------------------------
+// Ring depth: 8 stages (128 KiB) when the launch has the chip to itself; 3 stages (48 KiB) while a trailing
+// update runs on the other stream (lookahead) -- its workgroups hold 96 KiB of every CU's 160 KiB of LDS, and a
+// panel kernel that does not fit beside them waits for a whole tile (~130 us) instead of starting at once
+// (kernel trace: 127 us per launch with the deep ring against 65 us for the 16 KiB first-generation kernel).
 constexpr int SM_T = 64;                                   // tile edge
-constexpr int SM_STAGES = 8;
 constexpr int SM_STAGE_SLOTS = (SM_T + SM_T) * 8;          // 16-byte slots per stage (A then B): 16 KiB
+static thread_local int t_small_shallow = 0;
+GemmShallowScope::GemmShallowScope(bool on) : prev(t_small_shallow) { if (on) t_small_shallow = 1; }
+GemmShallowScope::~GemmShallowScope() { t_small_shallow = prev; }
+bool gemm_shallow_active() { return t_small_shallow != 0; }
 
 struct GemmSmallDev {
     double* C;
@@ -349,6 +356,7 @@ struct GemmSmallDev {
     int64_t diag_off;
 };
 
+template <int SM_STAGES>
 __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmSmallDev p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int ti = blockIdx.x / p.Tn, tj = blockIdx.x - ti * p.Tn;
@@ -391,12 +399,19 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmSmallDev p
         for (int j = 0; j < 2; ++j) acc[i][j] = d4{0., 0., 0., 0.};
 
     for (int c = 0; c < nch; ++c) {
-        // pieces of steps c + 1 .. may still fly: 4 per step in flight behind step c (at most 7 steps)
+        // pieces of steps c + 1 .. may still fly: 4 per step in flight behind step c (at most SM_STAGES - 1 steps)
         const int behind = min(nch - 1 - c, SM_STAGES - 1 - (c > 0 ? 1 : 0));
-        // s_waitcnt takes an immediate: the steady state (28 or 24 pieces behind) and the drain
-        if (behind >= 7) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
-        else if (behind == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // s_waitcnt takes an immediate: the steady state (first step / later steps) and the drain
+        if constexpr (SM_STAGES == 8) {
+            if (behind >= 7) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            else if (behind == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            static_assert(SM_STAGES == 3, "ring depth 8 or 3");
+            if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         if (c > 0 && c - 1 + SM_STAGES < nch) issue(c - 1 + SM_STAGES);      // the stage step c - 1 has just left
         const d2* sa = smem + (c % SM_STAGES) * SM_STAGE_SLOTS;
@@ -446,13 +461,14 @@ hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a) {
     p.C = a.C; p.A = a.A; p.B = a.B; p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
     p.Tm = (int)(a.M / SM_T); p.Tn = (int)(a.N / SM_T); p.nchunks = (int)(a.K / 16);
     p.lower = a.lower; p.diag_off = a.diag_off;
-    constexpr size_t lds = (size_t)SM_STAGES * SM_STAGE_SLOTS * 16;
+    constexpr size_t lds8 = (size_t)8 * SM_STAGE_SLOTS * 16, lds3 = (size_t)3 * SM_STAGE_SLOTS * 16;
     static PerDeviceOnce once;
     const hipError_t ea = once.run([&]() -> hipError_t {
-        return hipFuncSetAttribute((const void*)gemm_nt_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return hipFuncSetAttribute((const void*)gemm_nt_small_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
     });
     if (ea != hipSuccess) return ea;
-    hipLaunchKernelGGL(gemm_nt_small_kernel, dim3((unsigned)(p.Tm * p.Tn)), dim3(256), lds, s, p);
+    if (t_small_shallow) hipLaunchKernelGGL(gemm_nt_small_kernel<3>, dim3((unsigned)(p.Tm * p.Tn)), dim3(256), lds3, s, p);
+    else hipLaunchKernelGGL(gemm_nt_small_kernel<8>, dim3((unsigned)(p.Tm * p.Tn)), dim3(256), lds8, s, p);
     return hipGetLastError();
 }
 

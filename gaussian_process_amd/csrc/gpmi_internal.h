@@ -88,6 +88,13 @@ bool gemm_dma_eligible(const GemmArgs& a);
 hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
 // gemm_dma.hip: latency-oriented variant for launches with few tiles (64 x 64 tiles, eight K steps in flight)
 bool gemm_small_eligible(const GemmArgs& a);
+bool gemm_shallow_active();
+// while alive on this thread, small launches use the shallow ring (they run beside a trailing update)
+struct GemmShallowScope {
+    int prev;
+    explicit GemmShallowScope(bool on);
+    ~GemmShallowScope();
+};
 hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a);
 // number of tiles the launch actually computes (for flop accounting)
 double gemm_nt_flops(const GemmArgs& a);

@@ -35,13 +35,13 @@ constexpr int PB = 128;                 // panel block width
 constexpr int NT = PB / 16;             // 16 x 16 tiles per side
 constexpr int TILE_BYTES = 16 * 128;
 constexpr int NTILES = NT * (NT + 1) / 2;
+constexpr int POTRF_TILES = NT + 1;     // potrf128 keeps only the current step's operand tiles in LDS (18 KiB)
 constexpr int TRSM_ROWS = 64;            // rows per trsm128 workgroup pass (4 waves x 16)
 constexpr int SCR_LD = 18;              // doubles per scratch row (16-byte aligned rows, conflict-free row reads)
 
 __device__ __forceinline__ int kap(int g, int v) { return 2 * g + (v & 1) + 8 * (v >> 1); }
 // LDS row that holds matrix row n: rho^-1(n)
 __device__ __forceinline__ int rho_inv(int n) { return ((n >> 1) & 3) + 4 * (n & 1) + 8 * (n >> 3); }
-__device__ __forceinline__ int tile_index(int j, int k) { return j * (j + 1) / 2 + k; }   // k <= j
 
 __device__ __forceinline__ double readlane_d(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -236,13 +236,15 @@ __device__ __forceinline__ void stage_w_tile(const double* Ljj, int64_t ldl, d2*
 //   1  wave j       factors + inverts its diagonal tile, writes L_jj to memory and W_jj to LDS
 //   2  waves i > j  L_ij = S_ij W_jj^T (4 MFMAs), to memory and, negated, to LDS
 //   3  waves i > j  S_ik -= L_ij L_kj^T for k = j+1..i (4 MFMAs per tile), the diagonal chain first
-// Two barriers per step; a wave's tiles never leave its registers.
+// Two barriers per step; a wave's tiles never leave its registers.  LDS holds only the operands of the current
+// step (8 tile slots + W_jj + the scratch tile, 20 KiB), so the kernel fits on a CU beside a trailing-update
+// workgroup and starts at once under lookahead instead of waiting for a tile to finish.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, int64_t col_offset, int64_t* info,
                                                         unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    d2* tiles = reinterpret_cast<d2*>(smem);                                    // NTILES x 2 KiB
-    double* scratch = reinterpret_cast<double*>(smem + NTILES * TILE_BYTES);    // 16 x SCR_LD doubles
+    d2* tiles = reinterpret_cast<d2*>(smem);          // slot i: -L_ij of the current step j (block row i), slot 8: W_jj
+    double* scratch = reinterpret_cast<double*>(smem + POTRF_TILES * TILE_BYTES);    // 16 x SCR_LD doubles
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fr = lane & 15, fg = lane >> 4;
@@ -268,18 +270,18 @@ __global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, in
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             factor_diag_tile(scratch, A + (int64_t)(16 * j) * ld + 16 * j, ld,
-                             reinterpret_cast<double*>(tiles + tile_index(j, j) * 128), col_offset + 16 * j, info);
+                             reinterpret_cast<double*>(tiles + NT * 128), col_offset + 16 * j, info);
         }
         PANEL_STAMP(wave == j, 6 * j + 1);
         __syncthreads();
         PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 2);
         if (wave > j) {
             double a[4], z[4] = {0., 0., 0., 0.};
-            load_afrag(tiles + tile_index(j, j) * 128, lane, a);
+            load_afrag(tiles + NT * 128, lane, a);
             tile_mma(a, xt[j], z);
 #pragma unroll
             for (int v = 0; v < 4; ++v) xt[j][v] = z[v];
-            publish_tile(tiles + tile_index(wave, j) * 128, lane, xt[j], -1.0);
+            publish_tile(tiles + wave * 128, lane, xt[j], -1.0);
             store_xtile(A + (int64_t)(16 * wave) * ld + 16 * j, ld, lane, xt[j]);
         }
         PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 3);
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, in
             for (int k = j + 1; k < NT; ++k) {
                 if (k <= wave) {
                     double a[4];
-                    load_afrag(tiles + tile_index(k, j) * 128, lane, a);
+                    load_afrag(tiles + k * 128, lane, a);
                     tile_mma(a, xt[j], xt[k]);
                 }
             }
@@ -308,12 +310,28 @@ __global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, in
 // in 64 registers:
 //   for j = 0..7:  X_j <- X_j W_jj^T;   X_k -= X_j L_kj^T  for k > j         (144 MFMAs per 16 rows)
 // ---------------------------------------------------------------------------
+// PHASE -1: the whole solve in one launch (36 operand tiles, 72 KiB of LDS).
+// PHASE 0 / 1: the same solve as two launches -- columns 0..63 plus their updates of columns 64..127 (26 tiles,
+// 52 KiB), then columns 64..127 (10 tiles, 20 KiB) -- for launches that run beside a trailing update
+// (lookahead): its workgroups hold 96 KiB of every CU's 160 KiB, so only kernels with <= 64 KiB start at once.
+template <int PHASE>
+__device__ __forceinline__ constexpr int trsm_slot(int j, int k) {      // k <= j
+    if (PHASE == 0) return j < 4 ? j * (j + 1) / 2 + k : 10 + (j - 4) * 4 + k;
+    if (PHASE == 1) return (j - 4) * (j - 3) / 2 + (k - 4);
+    return j * (j + 1) / 2 + k;
+}
+template <int PHASE> constexpr int trsm_tiles() { return PHASE == 0 ? 26 : PHASE == 1 ? 10 : NTILES; }
+
+template <int PHASE>
 __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_t ldl, double* X, int64_t ldx,
                                                           int64_t nslabs, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     d2* tiles = reinterpret_cast<d2*>(smem);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int J0 = PHASE == 1 ? 4 : 0;             // first / one past last column tile this launch solves
+    constexpr int J1 = PHASE == 0 ? 4 : NT;
+    constexpr int T0 = PHASE == 1 ? 4 : 0;             // first column tile this launch touches
 #define PANEL_STAMP(cond, idx) if (stamps && (cond) && lane == 0) stamps[idx] = __builtin_amdgcn_s_memtime()
     PANEL_STAMP(blockIdx.x == 0 && wave == 0, 56);
 
@@ -323,27 +341,29 @@ __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_
     if (slab < nslabs) {
         const double* Xr = X + (slab * TRSM_ROWS + 16 * wave) * ldx;
 #pragma unroll
-        for (int k = 0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
+        for (int k = T0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
     }
-    // ---- stage L: wave w takes the off-diagonal tiles t = w, w + 4, ... and the diagonal tiles w, w + 4
+    // ---- stage L: the off-diagonal tiles of this phase round-robin over the waves, then the diagonal ones
     {
         int t = 0;
 #pragma unroll
         for (int j = 1; j < NT; ++j)
 #pragma unroll
-            for (int k = 0; k < j; ++k, ++t) {
-                if ((t & 3) == wave) {
-                    double x[4];
-                    load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
-                    publish_tile(tiles + tile_index(j, k) * 128, lane, x, -1.0);
+            for (int k = 0; k < j; ++k) {
+                if (k >= J0 && k < J1) {
+                    if ((t & 3) == wave) {
+                        double x[4];
+                        load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
+                        publish_tile(tiles + trsm_slot<PHASE>(j, k) * 128, lane, x, -1.0);
+                    }
+                    ++t;
                 }
             }
         PANEL_STAMP(blockIdx.x == 0 && wave == 0, 57);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int j = wave + 4 * q;
-            stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + tile_index(j, j) * 128, lane);
-        }
+        for (int j = J0; j < J1; ++j)
+            if (((j - J0) & 3) == wave)
+                stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + trsm_slot<PHASE>(j, j) * 128, lane);
     }
     PANEL_STAMP(blockIdx.x == 0 && wave == 0, 58);
     __syncthreads();
@@ -353,28 +373,28 @@ __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_
         double* Xr = X + (slab * TRSM_ROWS + 16 * wave) * ldx;
         if (slab != (int64_t)blockIdx.x) {
 #pragma unroll
-            for (int k = 0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
+            for (int k = T0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
         }
         if (stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PANEL_STAMP(blockIdx.x == 0 && wave == 0 && slab == blockIdx.x, 60);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+        for (int j = J0; j < J1; ++j) {
             double a[4], z[4] = {0., 0., 0., 0.};
-            load_afrag(tiles + tile_index(j, j) * 128, lane, a);
+            load_afrag(tiles + trsm_slot<PHASE>(j, j) * 128, lane, a);
             tile_mma(a, xt[j], z);
 #pragma unroll
             for (int v = 0; v < 4; ++v) xt[j][v] = z[v];
 #pragma unroll
             for (int k = j + 1; k < NT; ++k) {
                 double b[4];
-                load_afrag(tiles + tile_index(k, j) * 128, lane, b);
+                load_afrag(tiles + trsm_slot<PHASE>(k, j) * 128, lane, b);
                 tile_mma(b, xt[j], xt[k]);
             }
             __builtin_amdgcn_sched_barrier(0);      // one step's operand fragments at a time (register pressure)
         }
         PANEL_STAMP(blockIdx.x == 0 && wave == 0 && slab == blockIdx.x, 61);
 #pragma unroll
-        for (int k = 0; k < NT; ++k) store_xtile(Xr + 16 * k, ldx, lane, xt[k]);
+        for (int k = T0; k < NT; ++k) store_xtile(Xr + 16 * k, ldx, lane, xt[k]);
     }
     PANEL_STAMP(blockIdx.x == 0 && wave == 0, 62);
 #undef PANEL_STAMP
@@ -383,10 +403,7 @@ __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_
 static hipError_t panel_mfma_attrs() {
     static PerDeviceOnce once;
     return once.run([]() -> hipError_t {
-        hipError_t e = hipFuncSetAttribute((const void*)potrf128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           NTILES * TILE_BYTES + 16 * SCR_LD * 8);
-        if (e != hipSuccess) return e;
-        return hipFuncSetAttribute((const void*)trsm128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        return hipFuncSetAttribute((const void*)trsm128_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    NTILES * TILE_BYTES);
     });
 }
@@ -395,7 +412,7 @@ hipError_t launch_potrf128(hipStream_t s, double* A, int64_t ld, int64_t col_off
     if (ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15)) return hipErrorInvalidValue;
     hipError_t e = panel_mfma_attrs();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(512), NTILES * TILE_BYTES + 16 * SCR_LD * 8, s, A, ld, col_offset,
+    hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(512), POTRF_TILES * TILE_BYTES + 16 * SCR_LD * 8, s, A, ld, col_offset,
                        info_dev, tuning().panel_stamps);
     return hipGetLastError();
 }
@@ -408,7 +425,14 @@ hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X
     if (e != hipSuccess) return e;
     const int64_t nslabs = m / TRSM_ROWS;
     const unsigned grid = (unsigned)std::min<int64_t>(nslabs, 512);     // two workgroups per CU (72 KiB of LDS each)
-    hipLaunchKernelGGL(trsm128_kernel, dim3(grid), dim3(256), NTILES * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
+    if (gemm_shallow_active()) {            // beside a trailing update: two launches that fit next to its workgroups
+        hipLaunchKernelGGL(trsm128_kernel<0>, dim3(grid), dim3(256), trsm_tiles<0>() * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
+                           tuning().panel_stamps);
+        hipLaunchKernelGGL(trsm128_kernel<1>, dim3(grid), dim3(256), trsm_tiles<1>() * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
+                           tuning().panel_stamps);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(trsm128_kernel<-1>, dim3(grid), dim3(256), NTILES * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
                        tuning().panel_stamps);
     return hipGetLastError();
 }
