@@ -119,13 +119,18 @@ std::vector<int64_t> block_schedule(const gpmi_ctx* c, int64_t ncols) {
 // In-place blocked right-looking Cholesky of the leading ncols x ncols block of
 // A; rows ncols..nrows-1 are carried along (they end up multiplied by L^-T).
 //
-// With lookahead the trailing update of step k is split in two launches on the
-// main stream: (a) the next block column only, (b) the rest.  The panel stream
-// (high priority) factors panel k+1 as soon as (a) is done, i.e. concurrently
-// with (b), whose tiles it neither reads nor writes.  Dependencies:
-//   panel k  ->  (a)_k, (b)_k          (main waits on the panel event)
-//   (a)_k    ->  panel k+1             (panel stream waits on the column event)
-//   (b)_k    ->  (a)_{k+1}, (b)_{k+1}  (same stream)
+// With lookahead the trailing update of step k is split in two launches: (a) the next
+// block column only and (b) the rest.  From 49152 columns up both run on the main stream, the panel
+// stream (high priority) factors panel k+1 behind (a), concurrently with (b).  Below that (a) itself goes
+// on the panel stream, right behind panel k and in front of panel k+1, (b) on the main stream.  (a) and (b) write different columns
+// and both only read panel k, so they start together: the tail of (a) -- a launch whose last
+// tiles leave most CUs idle -- and the whole latency-bound panel k+1 run under (b).
+// Dependencies:
+//   panel k  ->  (a)_k                 (same stream)
+//   panel k  ->  (b)_k                 (main waits on the panel event)
+//   (a)_k    ->  panel k+1             (same stream)
+//   (b)_k    ->  (a)_{k+1}             (panel stream waits on the event behind (b)_k)
+//   (b)_k    ->  (b)_{k+1}             (same stream)
 hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows,
                             int64_t* info, bool account) {
     hipError_t e;
@@ -136,10 +141,17 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
     hipStream_t sp_ = la ? c->pstream : sm;
     GemmShallowScope shallow(la);                 // panel-internal updates run beside the trailing update
+    // (a) on the panel stream pays at mid sizes (N = 16384: -4 %, 32768: -1 %), where a launch's tail and the
+    // panel chain are a visible share of a step; at the headline size it is worth 0.4 % and would put two
+    // trailing-update launches in flight at once, which makes "time per launch" (the roofline figure) ambiguous
+    const bool col_on_panel = la && ncols < 49152;
     const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
     const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;   // panel 0 after the K build
-    auto trail = [&](int64_t r0, int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
+    // `counted`: the launch enters the roofline figures (GPMI_T_CHOL_TRAIL, its own kernel symbol).  Under lookahead
+    // only (b) does: (a) runs at the same time on the other stream, so summing both durations would count that
+    // time twice; (a) is launched under the generic symbol and timed with the panel it belongs to.
+    auto trail = [&](hipStream_t st, bool counted, int64_t r0, int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
         // C = A[r0.., c0..c0+ncol_upd) -= A[r0.., k..k+nb) * A[c0.., k..k+nb)^T, lower part
         GemmArgs g;
         g.C = A + r0 * ld + c0;
@@ -148,14 +160,14 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         g.ldc = g.lda = g.ldb = ld;
         g.M = nrows - r0; g.N = ncol_upd; g.K = nb;
         g.mode = 0; g.lower = 1; g.diag_off = r0 - c0;
-        g.role = 1;
+        g.role = counted ? 1 : 0;
         // the roofline figures are those of the LDS-DMA kernel: the last, small updates that
         // run on the first-generation kernel are timed into the scratch slot
         const bool dma = gemm_nt_routes_dma(g);
-        size_t sp = c->span_begin(dma ? slot_t : GPMI_T_COUNT - 1, sm);
-        hipError_t er = launch_gemm_nt(sm, g);
-        c->span_end(sp, sm);
-        if (account && dma) {
+        size_t sp = c->span_begin(counted ? (dma ? slot_t : GPMI_T_COUNT - 1) : slot_p, st);
+        hipError_t er = launch_gemm_nt(st, g);
+        c->span_end(sp, st);
+        if (account && dma && counted) {
             c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
             // algorithmic: the lower triangle of the real rows plus the one row that carries y
             c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_algorithmic_flops(g, ncols - r0 + 1);
@@ -163,6 +175,7 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         return er;
     };
     int64_t k = 0;
+    hipEvent_t ev_b = nullptr;                    // behind the last (b) on the main stream
     for (size_t step = 0; step < widths.size(); ++step) {
         const int64_t nb = widths[step];
         size_t sp = c->span_begin(slot_p, sp_);
@@ -174,14 +187,27 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         k = r0;
         if (r0 >= ncols) continue;
         if (!la) {
-            if ((e = trail(r0, r0, r0 - nb, nb, ncols - r0)) != hipSuccess) return e;
+            if ((e = trail(sm, true, r0, r0, r0 - nb, nb, ncols - r0)) != hipSuccess) return e;
             continue;
         }
         const int64_t nbn = widths[step + 1];
-        if ((e = trail(r0, r0, r0 - nb, nb, nbn)) != hipSuccess) return e;           // (a) next block column
-        if ((e = c->order(sm, sp_)) != hipSuccess) return e;
-        if (r0 + nbn < ncols &&
-            (e = trail(r0 + nbn, r0 + nbn, r0 - nb, nb, ncols - r0 - nbn)) != hipSuccess) return e;  // (b) rest
+        if (!col_on_panel) {
+            // large problems: (a) then (b) on the main stream, panel k+1 behind (a)
+            if ((e = trail(sm, true, r0, r0, r0 - nb, nb, nbn)) != hipSuccess) return e;
+            if ((e = c->order(sm, sp_)) != hipSuccess) return e;
+            if (r0 + nbn < ncols &&
+                (e = trail(sm, true, r0 + nbn, r0 + nbn, r0 - nb, nb, ncols - r0 - nbn)) != hipSuccess) return e;
+            continue;
+        }
+        // (a) next block column, behind panel k on the panel stream and behind (b) of the step before
+        if (ev_b && (e = hipStreamWaitEvent(sp_, ev_b, 0)) != hipSuccess) return e;
+        if ((e = trail(sp_, false, r0, r0, r0 - nb, nb, nbn)) != hipSuccess) return e;
+        if (r0 + nbn < ncols) {                                                          // (b) rest
+            if ((e = trail(sm, true, r0 + nbn, r0 + nbn, r0 - nb, nb, ncols - r0 - nbn)) != hipSuccess) return e;
+            ev_b = c->new_event();
+            if (!ev_b) return c->ev_error;
+            if ((e = hipEventRecord(ev_b, sm)) != hipSuccess) return e;
+        }
     }
     return hipSuccess;
 }
