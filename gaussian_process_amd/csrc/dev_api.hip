@@ -150,6 +150,26 @@ int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_de
     return GPMI_OK;
 }
 
+// backward substitution with a block as gpmi_dev_potrf_block leaves it (inverses in the diagonal tiles): 128 unknowns
+// per launch instead of 64 per pair of launches.  b is destroyed, the solution goes to x_dev (n doubles, no alias).
+int gpmi_dev_trsv_lt_fused(void* stream, const double* L_dev, int64_t ld, double* b_dev, double* x_dev, int64_t n) {
+    if (!L_dev || !b_dev || !x_dev || b_dev == x_dev) return fail_arg("gpmi_dev_trsv_lt_fused: null or aliased pointer");
+    if (n <= 0 || n % TILE || ld % 2) return fail_arg("gpmi_dev_trsv_lt_fused: n must be a positive multiple of 128, ld even");
+    HIP_TRY(launch_trsv_lt_fused((hipStream_t)stream, L_dev, ld, b_dev, x_dev, n));
+    return GPMI_OK;
+}
+
+// Tell the block primitives called from this thread that they run beside a trailing update on another stream
+// (the multi-rank driver's lookahead): the panel kernels then use their small-LDS forms (two-launch trsm128, shallow
+// ring for small GEMMs), which fit on a CU next to an update workgroup and start at once.  Results are the
+// same bits either way.  0 switches back.
+int gpmi_dev_set_concurrent(int on) {
+    static thread_local GemmShallowScope* scope = nullptr;
+    if (on && !scope) scope = new GemmShallowScope(true);
+    if (!on && scope) { delete scope; scope = nullptr; }
+    return GPMI_OK;
+}
+
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
                       const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
     if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");

@@ -95,7 +95,7 @@ struct gpmi_ctx {
     hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
     // options
     int64_t nb = 0;         // outer block width of the Cholesky (multiple of 128); 0 = by size
-    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 49152 ? 2048 : ncols >= 24576 ? 1024 : 512); }
+    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 49152 ? 2048 : ncols >= 12288 ? 1024 : 512); }
     int64_t ld_pad = 544;   // doubles added to every leading dimension
     int timing = 1;
     int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs

@@ -130,7 +130,17 @@ class HipBlockOps:
                                        self._p(x) if x is not None else None, self._p(y), self._p(scratch)))
 
     def trsv_lt(self, L, b):
-        check(self.lib.gpmi_dev_trsv_lt(self._stream(), self._p(L), self._ld(L), self._p(b), b.shape[0]))
+        """L^T x = b, x overwrites b (L as potrf_block leaves it)"""
+        n = b.shape[0]
+        if n % 128 == 0:
+            x = torch.empty_like(b)
+            check(self.lib.gpmi_dev_trsv_lt_fused(self._stream(), self._p(L), self._ld(L), self._p(b), self._p(x), n))
+            b.copy_(x)
+            return
+        check(self.lib.gpmi_dev_trsv_lt(self._stream(), self._p(L), self._ld(L), self._p(b), n))
+
+    def set_concurrent(self, on):
+        check(self.lib.gpmi_dev_set_concurrent(1 if on else 0))
 
     def sync(self):
         torch.cuda.synchronize(self.device)
@@ -229,15 +239,16 @@ class DistGP:
         self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         self.red = self._tensor(max(self.nloc, 1) + 1, 2)
         self.m = self._tensor(self.Np)
-        # per step: number of columns each 128-row band of my rows below block k updates
+        # per step: number of columns each 128-row band of my rows below block k updates (the part of the
+        # trailing matrix on or below the diagonal, to the 128-column tile)
         bands = NB // 128
         tabs, offs = [], []
         for k in range(self.T - 1):
             ls = self._lstart(k)
             offs.append(sum(len(t) for t in tabs))
             t = []
-            for li in range(ls, self.nloc):
-                t += [(self.my_blocks[li] - k) * NB] * bands
+            for li in range(ls, self.nloc):        # a block reaches its own diagonal: lower triangle only, per 128-row band
+                t += [(self.my_blocks[li] - k - 1) * NB + (q + 1) * 128 for q in range(bands)]
             if self.rank == self.ry:
                 t += [self.Np - (k + 1) * NB] * (YB // 128)
             tabs.append(t)
@@ -253,7 +264,7 @@ class DistGP:
             offs.append(sum(len(t) for t in tabs))
             t = []
             for li in range(ls, self.nloc):
-                t += [(self.my_blocks[li] - k - 1) * NB] * bands
+                t += [(self.my_blocks[li] - k - 2) * NB + (q + 1) * 128 for q in range(bands)]
             if self.rank == self.ry:
                 t += [self.Np - (k + 2) * NB] * (YB // 128)
             tabs.append(t)
@@ -512,6 +523,8 @@ class DistGP:
             A[self.yrow:self.yrow + YB, :self.Np].zero_()
             A[self.yrow, :self.N].copy_(self.y)
         T = self.T
+        if hasattr(ops, "set_concurrent"):
+            ops.set_concurrent(bool(self.lookahead))      # panel primitives run beside the update on other streams
         if self.lookahead >= 2:
             self._factor_critical_path_first()
         elif not self.lookahead:
@@ -548,6 +561,8 @@ class DistGP:
                         self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
                                      self.rowmapB[off:off + ln], self.rowmapB_h[off:off + ln])
             self._order(first_is_side=True)               # main waits for the last panel
+        if hasattr(ops, "set_concurrent"):
+            ops.set_concurrent(False)
         # not-PD: smallest failing global column over all ranks
         if self.coll:
             dist.all_reduce(self.info, op=dist.ReduceOp.MIN, group=self.group)
@@ -606,6 +621,8 @@ class DistGP:
         import time
         t_begin = time.perf_counter()
         ops, NB, G, A, V = self.ops, self.NB, self.G, self.A, self.V
+        if hasattr(ops, "set_concurrent"):
+            ops.set_concurrent(bool(self.lookahead))
         for li, b in enumerate(self.my_blocks):
             ops.rbf_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, self.d, self.n_p, NB,
                           self.sigma, self.ell, V[:, li * NB:(li + 1) * NB])
@@ -655,6 +672,8 @@ class DistGP:
                 if self.nloc - lb > 0:
                     ops.gemm_nt(V[:, lb * NB:self.nloc * NB], Xk, A[lb * NB:self.nloc * NB, c0:c0 + NB])
             self._order(first_is_side=True)
+        if hasattr(ops, "set_concurrent"):
+            ops.set_concurrent(False)
         self.dots.zero_()
         if self.nloc:
             ops.row_dots(V, self.nloc * NB, self.m_loc, self.dots[0], self.dots[1])

@@ -266,6 +266,12 @@ int gpmi_dev_gemv_t(void* stream, const double* A_dev, int64_t ld, int64_t nrows
                     const double* x_dev, double* y_dev, double* scratch_dev);
 /* backward substitution L^T x = b on an n x n lower block (x overwrites b), n % 64 == 0 */
 int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_dev, int64_t n);
+/* the same for a block as gpmi_dev_potrf_block leaves it (inverses in its diagonal tiles), n % 128 == 0: 128 unknowns
+ * per launch; b_dev is destroyed, the solution goes to x_dev (n doubles, must not alias b_dev) */
+int gpmi_dev_trsv_lt_fused(void* stream, const double* L_dev, int64_t ld, double* b_dev, double* x_dev, int64_t n);
+/* on != 0: the block primitives called from this thread run beside a trailing update on another stream (lookahead)
+ * and use their small-LDS forms, which fit on a CU next to an update workgroup; same results.  0 switches back. */
+int gpmi_dev_set_concurrent(int on);
 /* out[i] = sum_j V[i][j]*m[j] ; out2[i] = sum_j V[i][j]^2  (partial sums over
  * the columns this rank owns), i < nrows, j < ncols */
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows,
