@@ -20,10 +20,11 @@ build container by `oracle/make_golden.py` (which imports
 imported whole; make_golden.py executes the source text of their individual functions
 (`compute_mar_likelihood`, `gradient_ascent`, `bayesian_opt`, `UCB`, `EI`, `TS`, `overlap`,
 and the CO2 example's `covariance_function`, `compute_mar_likelihood`, `bayesian_opt`,
-`make_prediction`), which are valid Python 3 on their own, and the restatements here are
-checked against those outputs.  The loops that contain print statements
-(`tune_hyperparms_first`, `tune_hyperparms_second`, `PI`, `tune_hyperparameters_BO`) cannot
-be executed and are parity-unpinned beyond the functions they call.
+`make_prediction`), which are valid Python 3 on their own, and -- through lib2to3's print / repr
+fixers -- the ones with Python-2 print statements (`PI`, `random_gen_test_parms`,
+`tune_hyperparms_second`, the CO2 example's `tune_hyperparameters_BO`); the restatements here and
+the drop-ins' host logic are checked against those outputs (tests/golden/kernels_*.npz).
+`tune_hyperparms_first` is restated and pinned through the functions it calls.
 """
 from __future__ import annotations
 
