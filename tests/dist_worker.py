@@ -18,11 +18,17 @@ def main():
     import torch.distributed as dist
     import gp_oracle as O
     from gaussian_process_amd.dist import DistGP
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     if device == "cpu":
         torch.set_num_threads(2)
         from numpy_block_ops import NumpyBlockOps
         gp = DistGP(nb=nb, ops=NumpyBlockOps(), lookahead=int(os.environ.get("DISTGP_LOOKAHEAD", "1")))
+    elif device == "cuda_per_rank":        # one GPU per rank (boxes with >= world GPUs): the real RCCL path
+        torch.cuda.set_device(rank)
+        gp = DistGP(rank, nb=nb, lookahead=int(os.environ.get("DISTGP_LOOKAHEAD", "1")))
     else:
         torch.cuda.set_device(0)           # all ranks share the one GPU of the test box
         gp = DistGP(0, nb=nb, lookahead=int(os.environ.get("DISTGP_LOOKAHEAD", "1")))
@@ -59,7 +65,7 @@ def main():
             return np.array(vals), np.array(st)
     else:
         from gaussian_process_amd import GPContext
-        ctx = GPContext(0)
+        ctx = GPContext(rank if device == "cuda_per_rank" else 0)
         ctx.set_train(X, y)
         evaluate = ctx.lml_batch
     blml, bst = sharded_lml_batch(triples, evaluate)

@@ -114,6 +114,24 @@ def test_ranks_on_one_gpu_hip(oracle, tmp_path, world, N, d, n, nb, la):
     _check(res, oracle, N, d, n)
 
 
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs on one node (RCCL between ranks)")
+@pytest.mark.parametrize("la", [1, 2])
+def test_two_ranks_rccl_one_gpu_each(oracle, tmp_path, la):
+    """The real thing where the box has it: two ranks, one GPU each, backend "nccl" (RCCL over xGMI); same checks
+    as the gloo runs, every rank the same bits."""
+    res = _run(2, "nccl", "cuda_per_rank", tmp_path, 6144, 8, 128, 512, lookahead=la)
+    _check(res, oracle, 6144, 8, 128)
+
+
 @pytest.mark.gpu
 def test_rccl_collectives_on_a_world_of_one():
     """The RCCL call path itself (backend "nccl": broadcast, all_gather_into_tensor, int64 MIN all_reduce,
@@ -247,3 +265,22 @@ def test_bench_two_ranks_through_the_self_spawn_path():
     one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
     assert abs(one["lml"] - out["lml"]) <= 1e-12 * abs(one["lml"])
     assert "roofline" in one and "targets" in one
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run():
+    """the driver's other launch form: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 (each process
+    is one rank; no self-spawn), rehearsed on one GPU with gloo"""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPMI_BENCH_BACKEND="gloo", GPMI_BENCH_ONE_DEVICE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--size", "4096", "--ntest", "256", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0

@@ -813,3 +813,13 @@ def test_co2_tune_hyperparameters_BO_vs_reference_run(ctx):
     assert np.array_equal(chosen, g["co_next"])
     assert np.max(np.abs(ymax - g["co_ymax"]) / np.abs(g["co_ymax"])) <= 1e-9
     assert np.array_equal(best, g["co_best"])
+
+
+def test_device_info_and_panel_probe(ctx):
+    """the measurement entry points of the C-ABI answer sensibly on the box"""
+    di = ctx.device_info()
+    assert di["compute_units"] >= 64 and di["clock_khz"] > 5e5 and di["wavefront"] == 64 and di["global_mem_bytes"] > 1e10
+    us, st = ctx.probe_panel(0, reps=3, stamps=True)
+    assert 1.0 < us < 1e4 and int(st[49]) > int(st[48]) > 0          # potrf128: begin / end clock stamps
+    us, _ = ctx.probe_panel(1, m=512, reps=3)
+    assert 1.0 < us < 1e4
