@@ -170,6 +170,32 @@ int gpmi_dev_set_concurrent(int on) {
     return GPMI_OK;
 }
 
+// One row chunk of the gradient trace (tune_hyperparms_regression.py:43-57) on device pointers:
+//   out2[0] += sum_ij W_ij dK_ij/dl,  out2[1] += sum_ij W_ij dK_ij/dsigma,  W_ij = alpha_r[i] alpha_c[j] - kinv_sign * Kinv[i - row0][j]
+// over rows row0 .. row0 + nrows and ALL N columns (dK recomputed from X).  The multi-rank driver calls it once per
+// row block with its own partial of -K_y^-1 (and alpha only on one rank), so nothing N x N is ever summed across
+// ranks.  partial_dev: workspace of 2 * ceil(nrows / 128) * ceil(N / 128) doubles; out2 is accumulated
+// (fixed order) on the stream.
+int gpmi_dev_grad_trace(void* stream, const double* X_dev, int64_t N, int64_t d, int64_t row0, int64_t nrows,
+                        const double* alpha_r_dev, const double* alpha_c_dev, const double* Kinv_dev, int64_t ld,
+                        double kinv_sign, double sigma, double ell, double* partial_dev, double* out2_dev) {
+    if (!X_dev || !alpha_r_dev || !alpha_c_dev || !Kinv_dev || !partial_dev || !out2_dev)
+        return fail_arg("gpmi_dev_grad_trace: null pointer");
+    if (N <= 0 || d <= 0 || row0 < 0 || nrows <= 0 || row0 + nrows > N || ld < N || !(ell != 0.0))
+        return fail_arg("gpmi_dev_grad_trace: bad dimensions");
+    GradArgs g;
+    g.A = g.B = X_dev; g.nA = g.nB = N; g.d = d; g.row0 = row0; g.nrows = nrows;
+    g.alpha_r = alpha_r_dev; g.alpha_c = alpha_c_dev;
+    g.Kinv = Kinv_dev; g.ld = ld; g.kinv_sign = kinv_sign;
+    g.coef = -.5 * (1 / (ell * ell)); g.sig2 = sigma * sigma; g.two_sigma = 2 * sigma;
+    g.inv_l3 = 1.0 / (ell * ell * ell);
+    g.tri = 0;
+    g.partial = partial_dev;
+    HIP_TRY(launch_grad_trace((hipStream_t)stream, g));
+    HIP_TRY(launch_sum_pairs((hipStream_t)stream, partial_dev, grad_trace_blocks(g), out2_dev));
+    return GPMI_OK;
+}
+
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
                       const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
     if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");

@@ -179,6 +179,8 @@ hipError_t launch_trsv_lt_fused(hipStream_t s, const double* L, int64_t ld, doub
 // y[c] = sum_r A[r][c] * x[r]; scratch: ceil(nrows/64) * ncols doubles
 hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nrows, int64_t ncols,
                          const double* x, double* y, double* scratch);
+// out2[0..1] += the sums of the even / odd entries of part (n pairs), fixed order
+hipError_t launch_sum_pairs(hipStream_t s, const double* part, int64_t n, double* out2);
 // fill helpers
 hipError_t launch_fill_rows(hipStream_t s, double* A, int64_t ld, int64_t nrows, int64_t ncols,
                             double value);

@@ -304,6 +304,26 @@ hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nro
     return hipGetLastError();
 }
 
+// out2[0] += sum_b part[2b], out2[1] += sum_b part[2b+1], one thread, fixed order (per-tile partials of the
+// gradient trace: a few hundred to a few thousand entries)
+__global__ void sum_pairs_kernel(const double* part, int64_t n, double* out2) {
+    __shared__ double sh[2][256];
+    double a = 0., b = 0.;
+    for (int64_t i = threadIdx.x; i < n; i += 256) { a += part[2 * i]; b += part[2 * i + 1]; }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sa = 0., sb = 0.;
+        for (int t = 0; t < 256; ++t) { sa += sh[0][t]; sb += sh[1][t]; }
+        out2[0] += sa; out2[1] += sb;
+    }
+}
+
+hipError_t launch_sum_pairs(hipStream_t s, const double* part, int64_t n, double* out2) {
+    hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, part, n, out2);
+    return hipGetLastError();
+}
+
 // ---- fills / extraction --------------------------------------------------------
 __global__ void fill_rows_kernel(double* A, int64_t ld, int64_t ncols, double value) {
     double* row = A + (int64_t)blockIdx.y * ld;

@@ -139,6 +139,13 @@ class HipBlockOps:
             return
         check(self.lib.gpmi_dev_trsv_lt(self._stream(), self._p(L), self._ld(L), self._p(b), n))
 
+    def grad_trace(self, X, N, d, row0, nrows, alpha_r, alpha_c, Kinv, kinv_sign, sigma, ell, partial, out2):
+        """out2[0:2] += sum_ij (alpha_r[i] alpha_c[j] - kinv_sign * Kinv[i - row0][j]) * (dK_ij/dl, dK_ij/dsigma)
+        over rows row0 .. row0 + nrows and all N columns (tune_hyperparms_regression.py:43-57)"""
+        check(self.lib.gpmi_dev_grad_trace(self._stream(), self._p(X), N, d, row0, nrows, self._p(alpha_r), self._p(alpha_c),
+                                           self._p(Kinv), self._ld(Kinv), float(kinv_sign), float(sigma), float(ell),
+                                           self._p(partial), self._p(out2)))
+
     def set_concurrent(self, on):
         check(self.lib.gpmi_dev_set_concurrent(1 if on else 0))
 
@@ -725,6 +732,72 @@ class DistGP:
             err.bad_pivot = bad + 1
             raise err
         return np.tril(P[:self.n, :self.n].cpu().numpy())
+
+    # ------------------------------------------------------------------ LML gradient (f2)
+    def lml_grad(self):
+        """(dLML/dl, dLML/dsigma) = .5 * trace((alpha alpha^T - K_y^-1) dK/dtheta) at the resident factorisation
+        (tune_hyperparms_regression.py:43-57, :144) with L distributed.  U = L^-T is formed by the predict sweep on
+        the identity (rank r ends up with ITS column blocks of U, upper triangular); K_y^-1 = U U^T is a sum over
+        columns, so every rank owns an additive part of it: per row block it forms -U_r[rows] U_r^T with one MFMA
+        GEMM into an nb x N scratch and feeds the fused trace kernel -- nothing N x N is ever summed across ranks,
+        the alpha alpha^T term is added on rank 0 only, and the 2 x G partial traces are summed in rank order."""
+        if not self.have_factor:
+            raise ValueError("no factorisation resident (call factorize)")
+        ops, NB, G, A, T, Np = self.ops, self.NB, self.G, self.A, self.T, self.Np
+        alpha = self.alpha()                                   # full vector, every rank
+        a_full = self._tensor(Np)
+        a_full.zero_()
+        a_full[:self.N].copy_(torch.from_numpy(alpha).to(self.dev))
+        a_row = a_full if self.rank == 0 else torch.zeros_like(a_full)
+        ncl = max(self.nloc, 1) * NB
+        U = self._tensor(Np, ncl + self.ld_pad)
+        U.zero_()
+        for li, b in enumerate(self.my_blocks):                # my columns of the identity
+            U[b * NB:(b + 1) * NB, li * NB:(li + 1) * NB].diagonal().fill_(1.0)
+        Xk = self._tensor(Np, NB)
+        # ---- U^T sweep: column block k of U (rows < (k+1) NB are non-zero) <- block * L_kk^-T, then the later blocks
+        for k in range(T):
+            m = (k + 1) * NB
+            if self.rank == k % G:
+                li = k // G
+                blk = U[:m, li * NB:(li + 1) * NB]
+                ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
+                if self.coll:
+                    Xk[:m].copy_(blk)
+            if k == T - 1:
+                break
+            if self.coll:
+                dist.broadcast(Xk[:m], src=self._src(k % G), group=self.group)
+            src = Xk[:m] if self.coll else U[:m, (k // G) * NB:(k // G + 1) * NB]
+            ls = self._lstart(k)
+            if self.nloc - ls > 0:
+                ops.gemm_nt(U[:m, ls * NB:self.nloc * NB], src, A[ls * NB:self.nloc * NB, k * NB:(k + 1) * NB])
+        # ---- partial traces, one row block of (my part of) -K_y^-1 at a time
+        scratch = self._tensor(NB, Np + self.ld_pad)
+        nblk = (NB // 128) * (Np // 128)
+        partial = self._tensor(2 * nblk)
+        out2 = self._tensor(2)
+        out2.zero_()
+        for a in range(T):
+            lo = self._lstart(a - 1) if a > 0 else 0           # my first column block with global index >= a
+            scratch.zero_()
+            if self.nloc - lo > 0:                             # row a of U is zero left of its own diagonal block
+                ops.gemm_nt(scratch[:, :Np], U[a * NB:(a + 1) * NB, lo * NB:self.nloc * NB], U[:, lo * NB:self.nloc * NB])
+            nrows = min(NB, self.N - a * NB)
+            if nrows > 0:
+                ops.grad_trace(self.X, self.N, self.d, a * NB, nrows, a_row, a_full, scratch, -1.0, self.sigma, self.ell,
+                               partial, out2)
+        if self.coll:
+            allp = self._tensor(G * 2)
+            dist.all_gather_into_tensor(allp, out2, group=self.group)
+        else:
+            allp = out2
+        allp = allp.view(G, 2).cpu().numpy()
+        sl = ss = 0.0
+        for r in range(G):                                     # fixed order
+            sl += float(allp[r, 0])
+            ss += float(allp[r, 1])
+        return .5 * sl, .5 * ss
 
     # ------------------------------------------------------------------ alpha
     def alpha(self):

@@ -272,6 +272,14 @@ int gpmi_dev_trsv_lt_fused(void* stream, const double* L_dev, int64_t ld, double
 /* on != 0: the block primitives called from this thread run beside a trailing update on another stream (lookahead)
  * and use their small-LDS forms, which fit on a CU next to an update workgroup; same results.  0 switches back. */
 int gpmi_dev_set_concurrent(int on);
+/* f2 on device pointers, one row chunk of the gradient trace (tune_hyperparms_regression.py:43-57):
+ *   out2[0] += sum_ij W_ij dK_ij/dl,  out2[1] += sum_ij W_ij dK_ij/dsigma,
+ *   W_ij = alpha_r[i] alpha_c[j] - kinv_sign * Kinv[(i - row0) * ld + j],  rows row0 .. row0 + nrows, all N columns.
+ * partial_dev: 2 * ceil(nrows / 128) * ceil(N / 128) doubles of workspace.  The multi-rank driver feeds it
+ * its own partial of -K_y^-1 row block by row block (DistGP.lml_grad). */
+int gpmi_dev_grad_trace(void* stream, const double* X_dev, int64_t N, int64_t d, int64_t row0, int64_t nrows,
+                        const double* alpha_r_dev, const double* alpha_c_dev, const double* Kinv_dev, int64_t ld,
+                        double kinv_sign, double sigma, double ell, double* partial_dev, double* out2_dev);
 /* out[i] = sum_j V[i][j]*m[j] ; out2[i] = sum_j V[i][j]^2  (partial sums over
  * the columns this rank owns), i < nrows, j < ncols */
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows,

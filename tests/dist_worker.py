@@ -37,6 +37,7 @@ def main():
     mu, var = gp.predict(Xs, want_sd=False)
     alpha = gp.alpha()
     Lp = gp.post_chol(1e-6)                                       # f1 distributed (GP_regression.py:153-154)
+    g_l, g_s = gp.lml_grad()                                      # f2 distributed (tune_hyperparms_regression.py:43-57)
     # the drop-in surface routed to the multi-rank driver (additive dist= / n_gpus= keywords)
     from gaussian_process_amd import GP_regression as G
     from gaussian_process_amd import tune_hyperparms_regression as T
@@ -71,7 +72,7 @@ def main():
     blml, bst = sharded_lml_batch(triples, evaluate)
     np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised,
              blml=blml, bst=bst, triples=triples, alpha=alpha, Lp=Lp, d_mu=d_mu, d_sd=d_sd, d_fp=d_fp, d_lml=d_lml,
-             d_cml=d_cml)
+             d_cml=d_cml, g_l=g_l, g_s=g_s)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -95,6 +95,17 @@ class NumpyBlockOps:
             w_t = min((int(nc[q]) + 127) // 128 * 128, c.shape[1])
             c[rs, :w_t] -= a[rs] @ b[:w_t].T
 
+    def grad_trace(self, X, N, d, row0, nrows, alpha_r, alpha_c, Kinv, kinv_sign, sigma, ell, partial, out2):
+        Xn = self._a(X)[:N]
+        rows = slice(row0, row0 + nrows)
+        sq = ((Xn[rows][:, :, None] - Xn[:, :, None].T) ** 2).sum(1)                 # tune_hyperparms_regression.py:43
+        e = np.exp(-.5 * sq / ell ** 2)
+        Dl, Ds = sigma ** 2 * e * (sq / ell ** 3), 2 * sigma * e                     # :54, :48
+        W = np.outer(self._a(alpha_r)[rows], self._a(alpha_c)[:N]) - kinv_sign * self._a(Kinv)[:nrows, :N]
+        o = self._a(out2)
+        o[0] += float(np.sum(W * Dl))
+        o[1] += float(np.sum(W * Ds))
+
     def logdiag_sumsq(self, A, n, x, nx, out2):
         o = self._a(out2)
         o[0] = np.log(np.diagonal(self._a(A))[:n]).sum() if A is not None else 0.0

@@ -50,6 +50,14 @@ def _check(res, oracle, N, d, n):
         Lref = np.linalg.cholesky(pref["K_ss"] + 1e-6 * np.eye(n) - pref["v"].T @ pref["v"])
         np.random.seed(123)
         fref = pref["mu"].reshape(-1, 1) + Lref @ np.random.normal(size=(n, 2))
+    if N <= 2200:      # f2 distributed against the oracle's statement-by-statement gradient (:43-57, :144)
+        _, l_var, sigma_var, alpha_o, K_y = oracle.lml_and_gradient(X, y, 1.0, ell)
+        sq = ((X[:, :, None] - X[:, :, None].T) ** 2).sum(1)
+        e = np.exp(-.5 * sq / ell ** 2)
+        scale_l = .5 * abs(alpha_o @ (e * sq / ell ** 3) @ alpha_o) + .5 * abs(np.sum(K_y * (e * sq / ell ** 3)))
+        scale_s = .5 * abs(alpha_o @ (2 * e) @ alpha_o) + .5 * abs(np.sum(K_y * (2 * e)))
+        for r in res:
+            assert abs(r["g_l"] - l_var) <= 1e-9 * scale_l and abs(r["g_s"] - sigma_var) <= 1e-9 * scale_s
     for r in res:
         if pref is not None:
             assert np.max(np.abs(r["Lp"] - Lref)) <= 1e-6
@@ -72,7 +80,7 @@ def _check(res, oracle, N, d, n):
                 want = want_batch[t]
                 assert abs(r["blml"][t] - want) <= 1e-10 * abs(want) and r["bst"][t] == 0
     for r in res[1:]:                      # every rank returns the same bits
-        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml", "alpha", "Lp", "d_fp"):
+        for key in ("lml", "mu", "var", "lml2", "mu2", "sd2", "blml", "alpha", "Lp", "d_fp", "g_l", "g_s"):
             assert np.array_equal(r[key], res[0][key], equal_nan=True), key
 
 
