@@ -229,6 +229,53 @@ __device__ __forceinline__ void cov_store(const RbfDev& p, int64_t gr, int64_t g
     *reinterpret_cast<d2*>(dst) = d2{v0, v1};
 }
 
+template <class FA, class FB>
+__device__ __forceinline__ double cov_other_acc(const RbfDev& p, FA a, FB b, bool diag) {
+    if (p.kind == 1) {                         // lin_kernel: np.dot(a - c, b.T - c)
+        double s = 0.0;
+        for (int k = 0; k < p.d; ++k) s = s + (a(k) - p.kp0) * (b(k) - p.kp0);
+        return s;
+    }
+    if (p.kind == 3) {
+        const double* th = p.kpv;              // th[i] = theta_(i+1)
+        const double sq = sq_pw_small(a, b, p.d);                                    // CO2_example.py:76 / :83 (d <= 128)
+        const double r = sqrt(sq);                                                   // :77 / :85
+        const double k1 = (th[0] * th[0]) * exp(-.5 * sq / (th[1] * th[1]));         // :17
+        const double first = -.5 * sq / (th[3] * th[3]);                             // :30
+        const double sn = sin(M_PI * r) / th[4];
+        const double second = -2 * (sn * sn);                                        // :31
+        const double k2 = (th[2] * th[2]) * exp(first + second);                     // :32
+        const double item = 1 + .5 * sq / (th[7] * (th[6] * th[6]));                 // :44
+        const double k3 = (th[5] * th[5]) * (1.0 / pow(item, th[7]));                // :45-46
+        const double delta = (p.delta_square && diag) ? 1.0 : 0.0;                   // :58-62
+        const double k4 = (th[8] * th[8]) * exp(-.5 * sq / (th[9] * th[9])) + (th[10] * th[10]) * delta;   // :63-64
+        return ((k1 + k2) + k3) + k4;                                                // :86-89
+    }
+    // per_kernel (1-D): exp(-2 * sin(pi * |a-b| / p)**2 / l**2), evaluated in the reference's order
+    const double t = fabs(a(0) - b(0));
+    const double sn = sin(M_PI * t / p.kp0);
+    return exp(-2.0 * (sn * sn) / (p.kp1 * p.kp1));
+}
+
+__device__ __forceinline__ double cov_other(const RbfDev& p, const double* a, const double* b, bool diag) {
+    if (p.kind == 3 && p.d > 128) {            // recursive-halving order above 128 terms
+        const double* th = p.kpv;
+        const double sq = sq_pw_global(a, b, p.d);
+        const double r = sqrt(sq);
+        const double k1 = (th[0] * th[0]) * exp(-.5 * sq / (th[1] * th[1]));
+        const double first = -.5 * sq / (th[3] * th[3]);
+        const double sn = sin(M_PI * r) / th[4];
+        const double second = -2 * (sn * sn);
+        const double k2 = (th[2] * th[2]) * exp(first + second);
+        const double item = 1 + .5 * sq / (th[7] * (th[6] * th[6]));
+        const double k3 = (th[5] * th[5]) * (1.0 / pow(item, th[7]));
+        const double delta = (p.delta_square && diag) ? 1.0 : 0.0;
+        const double k4 = (th[8] * th[8]) * exp(-.5 * sq / (th[9] * th[9])) + (th[10] * th[10]) * delta;
+        return ((k1 + k2) + k3) + k4;
+    }
+    return cov_other_acc(p, [&](int k) { return a[k]; }, [&](int k) { return b[k]; }, diag);
+}
+
 // D > 0: d == D at compile time (b columns in registers); D == 0: runtime d <= LDS_MAXD
 template <int D>
 __global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
@@ -271,6 +318,22 @@ __global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
             rbf_finish(p, grow0 + 32 * rg + r, gc, s0, s1, out0 + (int64_t)r * p.ld);
         }
     } else {
+        if (p.kind != 0) {
+            // the reference's other covariance functions through the same tile: X rows of both tile edges in LDS
+            // (a: broadcast reads, b: conflict-free column reads), one column pair x 32 rows per thread
+            for (int r = 0; r < 32; ++r) {
+                const int64_t gr = grow0 + 32 * rg + r;
+                const double* ar = &As[(32 * rg + r) * d];
+                const double* bc = &Bs[2 * cp];
+                double v0 = 0., v1 = 0.;
+                if (gr < p.nA) {
+                    if (gc < p.nB) v0 = cov_other_acc(p, [&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT]; }, gr == gc);
+                    if (gc + 1 < p.nB) v1 = cov_other_acc(p, [&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT + 1]; }, gr == gc + 1);
+                }
+                cov_store(p, gr, gc, v0, v1, out0 + (int64_t)r * p.ld);
+            }
+            return;
+        }
         for (int r = 0; r < 32; ++r) {
             const double* ar = &As[(32 * rg + r) * d];
             const double* bc = &Bs[2 * cp];
@@ -431,40 +494,13 @@ __global__ __launch_bounds__(256) void rbf_naive_kernel(const RbfDev p) {
     }
 }
 
-// The reference's other covariance functions, one column pair per
-// thread straight from global memory: these matrices are built once per fit, the work is in
-// the factorisation.
+// The reference's other covariance functions.  Up to d = 32 they run through
+// the LDS-staged tile kernel above (rbf_kernel<0>, kind != 0); cov_other_kernel below is the any-d fallback,
+// one column pair per thread straight from global memory.
 //   kind 1  lin_kernel                                   GP_regression.py:22-33
 //   kind 2  per_kernel (1-D)                             GP_regression.py:36-50
 //   kind 3  covariance_function = kernel_1 + kernel_2 + kernel_3 + kernel_4 (RBF + decaying
 //           periodic + rational quadratic + noise), any d             CO2_example.py:9-94
-__device__ __forceinline__ double cov_other(const RbfDev& p, const double* a, const double* b, bool diag) {
-    if (p.kind == 1) {                         // lin_kernel: np.dot(a - c, b.T - c)
-        double s = 0.0;
-        for (int k = 0; k < p.d; ++k) s = s + (a[k] - p.kp0) * (b[k] - p.kp0);
-        return s;
-    }
-    if (p.kind == 3) {
-        const double* th = p.kpv;              // th[i] = theta_(i+1)
-        const double sq = sq_pw_global(a, b, p.d);                                   // CO2_example.py:76 / :83
-        const double r = sqrt(sq);                                                   // :77 / :85
-        const double k1 = (th[0] * th[0]) * exp(-.5 * sq / (th[1] * th[1]));         // :17
-        const double first = -.5 * sq / (th[3] * th[3]);                             // :30
-        const double sn = sin(M_PI * r) / th[4];
-        const double second = -2 * (sn * sn);                                        // :31
-        const double k2 = (th[2] * th[2]) * exp(first + second);                     // :32
-        const double item = 1 + .5 * sq / (th[7] * (th[6] * th[6]));                 // :44
-        const double k3 = (th[5] * th[5]) * (1.0 / pow(item, th[7]));                // :45-46
-        const double delta = (p.delta_square && diag) ? 1.0 : 0.0;                   // :58-62
-        const double k4 = (th[8] * th[8]) * exp(-.5 * sq / (th[9] * th[9])) + (th[10] * th[10]) * delta;   // :63-64
-        return ((k1 + k2) + k3) + k4;                                                // :86-89
-    }
-    // per_kernel (1-D): exp(-2 * sin(pi * |a-b| / p)**2 / l**2), evaluated in the reference's order
-    const double t = fabs(a[0] - b[0]);
-    const double sn = sin(M_PI * t / p.kp0);
-    return exp(-2.0 * (sn * sn) / (p.kp1 * p.kp1));
-}
-
 __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
     int ti, tj;
     if (!rbf_map_tile(p, ti, tj)) return;
@@ -514,7 +550,9 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     dim3 grid((unsigned)nblk), block(256);
     const size_t lds = (size_t)2 * RT * a.d * sizeof(double);
     if (a.kind != 0) {
-        hipLaunchKernelGGL(cov_other_kernel, grid, block, 0, s, p);
+        // lin / per / CO2 composite: the LDS-staged tile kernel (d <= 32), straight from global memory above that
+        if (a.d <= LDS_MAXD) hipLaunchKernelGGL(rbf_kernel<0>, grid, block, lds, s, p);
+        else hipLaunchKernelGGL(cov_other_kernel, grid, block, 0, s, p);
         return hipGetLastError();
     }
     {
