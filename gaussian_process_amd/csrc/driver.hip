@@ -259,10 +259,10 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     r.max_sq = box_max_sq(c->boxX, c->boxX);
     r.out = A; r.ld = c->ldA;
     HIP_TRY(launch_rbf(s, r));
-    // the augmented rows: y then zeros
+    c->span_end(sp);                  // GPMI_T_KBUILD is the kernel-matrix build (a1 + a2) alone
+    // the augmented rows: y then zeros (a4 rides in the factorisation)
     HIP_TRY(launch_fill_rows(s, A + c->Np * c->ldA, c->ldA, TILE, c->Np, 0.0));
     HIP_TRY(launch_set_yrow(s, A + c->Np * c->ldA, c->y.as<double>(), c->N, c->Np));
-    c->span_end(sp);
 
     sp = c->span_begin(GPMI_T_CHOL);
     HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true));
