@@ -833,9 +833,9 @@ class DistGP:
             if self.rank == k % G:
                 li = k // G
                 rhs.copy_(self.m[c0:c0 + NB])
-                P = allp.view(G, NB)
-                for r in range(G):                     # fixed order
-                    rhs.sub_(P[r])
+                # one reduction kernel over the G contributions (a fixed tree for a given G and nb: the same
+                # bits on every run), not G tiny launches on the latency chain of the block
+                rhs.sub_(allp.view(G, NB).sum(dim=0))
                 ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs)
                 aloc[li * NB:(li + 1) * NB].copy_(rhs)
         # assemble the full vector in natural block order
