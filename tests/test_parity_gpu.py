@@ -823,3 +823,18 @@ def test_device_info_and_panel_probe(ctx):
     assert 1.0 < us < 1e4 and int(st[49]) > int(st[48]) > 0          # potrf128: begin / end clock stamps
     us, _ = ctx.probe_panel(1, m=512, reps=3)
     assert 1.0 < us < 1e4
+
+
+@pytest.mark.parametrize("N,d,n,ell,s2,sf", [(3001, 5, 77, 1.5, 5e-4, 1.0), (12289, 8, 130, 2.0, 5e-4, 1.0),
+                                             (13000, 2, 1000, 0.7, 5e-4, 0.8), (8191, 16, 64, 2.8, 1e-4, 1.0)])
+def test_ragged_sizes_across_the_lookahead_threshold(ctx, oracle, N, d, n, ell, s2, sf):
+    """sizes that are no multiple of anything, on both sides of the 12288-column lookahead threshold (two streams,
+    two-launch trsm128, next-column update on the panel stream): mean / variance / LML / alpha against the oracle"""
+    X, y, Xs = oracle.synthetic_problem(N, d, n, seed=N)
+    ref = oracle.fit_predict_feasible(X, Xs, y, sf, ell, s2)
+    lml = ctx.fit(X, y, sf, ell, s2)
+    mu, var = ctx.predict(Xs, want_sd=False)
+    assert np.max(np.abs(mu - ref["mu"])) <= MU_ATOL
+    assert np.max(np.abs(var - ref["var"])) <= VAR_ATOL
+    assert abs(lml - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
+    assert relmax(ctx.alpha(), ref["alpha"]) <= ALPHA_RTOL
