@@ -22,6 +22,7 @@
 //   s_waitcnt vmcnt(pieces of c+2 may fly), lgkmcnt(0) | s_barrier
 //   F1.x + read F0 <- stage (c+1)%3, k-pairs 0..3 | F1.y
 #include <algorithm>
+#include <cstdlib>
 
 #include "gpmi_internal.h"
 
@@ -342,7 +343,10 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
 constexpr int SM_T = 64;                                   // tile edge
 constexpr int SM_STAGE_SLOTS = (SM_T + SM_T) * 8;          // 16-byte slots per stage (A then B): 16 KiB
 static thread_local int t_small_shallow = 0;
-GemmShallowScope::GemmShallowScope(bool on) : prev(t_small_shallow) { if (on) t_small_shallow = 1; }
+GemmShallowScope::GemmShallowScope(bool on) : prev(t_small_shallow) {
+    static const int mode = getenv("GPMI_SHALLOW") ? atoi(getenv("GPMI_SHALLOW")) : 1;     // measurement only
+    if (on && mode) t_small_shallow = 1;
+}
 GemmShallowScope::~GemmShallowScope() { t_small_shallow = prev; }
 bool gemm_shallow_active() { return t_small_shallow != 0; }
 
