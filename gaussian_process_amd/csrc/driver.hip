@@ -99,16 +99,16 @@ std::vector<int64_t> block_schedule(const gpmi_ctx* c, int64_t ncols) {
     const int64_t NB = c->block(ncols);
     std::vector<int64_t> w;
     const bool ramp = c->nb == 0 && c->ramp && NB >= 1024 && ncols >= 8 * NB;
+    const bool up = ramp && (c->ramp & 1), down = ramp && (c->ramp & 2);
+    const int64_t tail = (c->ramp >> 4) ? (c->ramp >> 4) : 3;       // blocks at the end that run at half width
     int64_t done = 0;
     while (done < ncols) {
         int64_t nb = NB;
-        if (ramp) {
-            const int64_t left = ncols - done;
-            if (w.size() < 2) nb = NB / 4;
-            else if (w.size() < 3) nb = NB / 2;
-            else if (left <= NB) nb = NB / 4;
-            else if (left <= 3 * NB) nb = NB / 2;
-        }
+        const int64_t left = ncols - done;
+        if (up && w.size() < 2) nb = NB / 4;
+        else if (up && w.size() < 3) nb = NB / 2;
+        else if (down && left <= NB && (c->ramp & 4)) nb = NB / 4;
+        else if (down && left <= tail * NB) nb = NB / 2;
         nb = std::min(nb, ncols - done);
         w.push_back(nb);
         done += nb;

@@ -99,7 +99,7 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 8) return fail_arg("lanes must be 0 (by size) .. 8");
         c->lanes = (int)value;
     } else if (!strcmp(name, "ramp")) {
-        c->ramp = value ? 1 : 0;
+        c->ramp = (int)value;
     } else if (!strcmp(name, "gemm_small_tiles")) {
         c->tune.gemm_small_tiles = value ? 1 : 0;
     } else if (!strcmp(name, "trsm_wave")) {

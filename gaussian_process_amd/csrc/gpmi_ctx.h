@@ -101,7 +101,8 @@ struct gpmi_ctx {
     int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
     int lanes = 0;          // gpmi_lml_batch: factorisations in flight (0 = by size)
     std::vector<gpmi_ctx*> lane_ctx;   // the extra lanes (own streams and workspaces), created on demand
-    int ramp = 0;           // block widths ramp up at the start and down at the end of the sweep (measured: 0.4 % slower at N = 65536, off)
+    int ramp = 0;           // block-width schedule, bit mask: 1 ramp up at the start, 2 half width over the last blocks (count in bits 4.., default 3),
+                            // 4 quarter width for the last block (measured: ramp up 0.4 % slower at N = 65536; ramp down within noise at N = 16384 / 32768: off)
     gpmi::Tuning tune;      // kernel-selection options of this context (installed per call: gpmi::TuneScope)
     // training set / factor
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
