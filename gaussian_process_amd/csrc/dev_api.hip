@@ -159,6 +159,16 @@ int gpmi_dev_trsv_lt_fused(void* stream, const double* L_dev, int64_t ld, double
     return GPMI_OK;
 }
 
+// the same through the full inverses of the 128 x 128 diagonal blocks (launch_vinv128 writes them into the blocks' upper
+// triangles when invert != 0; later calls on the same factored block pass 0): one product per 128 unknowns
+int gpmi_dev_trsv_lt_vinv(void* stream, double* L_dev, int64_t ld, double* b_dev, double* x_dev, int64_t n, int invert) {
+    if (!L_dev || !b_dev || !x_dev || b_dev == x_dev) return fail_arg("gpmi_dev_trsv_lt_vinv: null or aliased pointer");
+    if (n <= 0 || n % TILE || ld % 2) return fail_arg("gpmi_dev_trsv_lt_vinv: n must be a positive multiple of 128, ld even");
+    if (invert) HIP_TRY(launch_vinv128((hipStream_t)stream, L_dev, ld, n));
+    HIP_TRY(launch_trsv_lt_vinv((hipStream_t)stream, L_dev, ld, b_dev, x_dev, n));
+    return GPMI_OK;
+}
+
 // Tell the block primitives called from this thread that they run beside a trailing update on another stream
 // (the multi-rank driver's lookahead): the panel kernels then use their small-LDS forms (two-launch trsm128, shallow
 // ring for small GEMMs), which fit on a CU next to an update workgroup and start at once.  Results are the

@@ -106,6 +106,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->tune.trsm_wave = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_small_dma")) {
         c->tune.gemm_small_dma = value ? 1 : 0;
+    } else if (!strcmp(name, "trsv_vinv")) {
+        c->tune.trsv_vinv = value ? 1 : 0;
     } else if (!strcmp(name, "panel_fused")) {
         c->tune.panel_fused = value ? 1 : 0;
     } else if (!strcmp(name, "rbf_blocks")) {
@@ -304,6 +306,19 @@ int gpmi_get_factor_block(gpmi_ctx* c, int64_t r0, int64_t r1, int64_t c0, int64
     return GPMI_OK;
 }
 
+// L^T x = b on the resident fused factor (a5): the first call after a factorisation inverts the 128 x 128 diagonal
+// blocks into their upper triangles (one launch, all blocks at once), every call then runs one product per block
+static hipError_t backward_solve_fused(gpmi_ctx* c, double* b, double* xout) {
+    double* A = c->A.as<double>();
+    if (!tuning().trsv_vinv) return launch_trsv_lt_fused(c->stream, A, c->ldA, b, xout, c->Np);
+    if (!c->have_vinv) {
+        const hipError_t e = launch_vinv128(c->stream, A, c->ldA, c->Np);
+        if (e != hipSuccess) return e;
+        c->have_vinv = true;
+    }
+    return launch_trsv_lt_vinv(c->stream, A, c->ldA, b, xout, c->Np);
+}
+
 int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
     if (!c || !alpha_out) return fail_arg("gpmi_get_alpha: null argument");
     if (!c->have_factor) return fail_arg("gpmi_get_alpha: no factorisation resident");
@@ -318,7 +333,7 @@ int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
                            hipMemcpyDeviceToDevice, s));
     size_t sp = c->span_begin(GPMI_T_ALPHA);
     if (c->factor_fused) {
-        HIP_TRY(launch_trsv_lt_fused(s, c->A.as<double>(), c->ldA, x, x + c->Np, c->Np));
+        HIP_TRY(backward_solve_fused(c, x, x + c->Np));
         x += c->Np;
     } else {
         HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), c->ldA, x, c->Np));
@@ -443,7 +458,7 @@ int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
     double* alpha = c->vec.as<double>();
     HIP_TRY(hipMemcpyAsync(alpha, c->A.as<double>() + Np * ld, (size_t)Np * 8, hipMemcpyDeviceToDevice, s));
     if (c->factor_fused) {
-        HIP_TRY(launch_trsv_lt_fused(s, c->A.as<double>(), ld, alpha, alpha + Np, Np));
+        HIP_TRY(backward_solve_fused(c, alpha, alpha + Np));
         alpha += Np;
     } else {
         HIP_TRY(launch_trsv_lt(s, c->A.as<double>(), ld, alpha, Np));

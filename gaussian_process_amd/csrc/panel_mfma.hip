@@ -322,6 +322,33 @@ __device__ __forceinline__ constexpr int trsm_slot(int j, int k) {      // k <= 
 }
 template <int PHASE> constexpr int trsm_tiles() { return PHASE == 0 ? 26 : PHASE == 1 ? 10 : NTILES; }
 
+// Staging of a 128 x 128 factored diagonal block as A operands (4 waves): the off-diagonal tiles of this phase,
+// negated, round-robin over the waves, then the stored inverses of the diagonal tiles.
+template <int PHASE>
+__device__ __forceinline__ void stage_l_tiles(const double* L, int64_t ldl, d2* tiles, int lane, int wave,
+                                              unsigned long long* stamps) {
+    constexpr int J0 = PHASE == 1 ? 4 : 0, J1 = PHASE == 0 ? 4 : NT;
+    int t = 0;
+#pragma unroll
+    for (int j = 1; j < NT; ++j)
+#pragma unroll
+        for (int k = 0; k < j; ++k) {
+            if (k >= J0 && k < J1) {
+                if ((t & 3) == wave) {
+                    double x[4];
+                    load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
+                    publish_tile(tiles + trsm_slot<PHASE>(j, k) * 128, lane, x, -1.0);
+                }
+                ++t;
+            }
+        }
+    if (stamps && wave == 0 && lane == 0) stamps[57] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int j = J0; j < J1; ++j)
+        if (((j - J0) & 3) == wave)
+            stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + trsm_slot<PHASE>(j, j) * 128, lane);
+}
+
 template <int PHASE>
 __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_t ldl, double* X, int64_t ldx,
                                                           int64_t nslabs, unsigned long long* stamps) {
@@ -343,28 +370,7 @@ __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_
 #pragma unroll
         for (int k = T0; k < NT; ++k) load_xtile(Xr + 16 * k, ldx, lane, xt[k]);
     }
-    // ---- stage L: the off-diagonal tiles of this phase round-robin over the waves, then the diagonal ones
-    {
-        int t = 0;
-#pragma unroll
-        for (int j = 1; j < NT; ++j)
-#pragma unroll
-            for (int k = 0; k < j; ++k) {
-                if (k >= J0 && k < J1) {
-                    if ((t & 3) == wave) {
-                        double x[4];
-                        load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
-                        publish_tile(tiles + trsm_slot<PHASE>(j, k) * 128, lane, x, -1.0);
-                    }
-                    ++t;
-                }
-            }
-        PANEL_STAMP(blockIdx.x == 0 && wave == 0, 57);
-#pragma unroll
-        for (int j = J0; j < J1; ++j)
-            if (((j - J0) & 3) == wave)
-                stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + trsm_slot<PHASE>(j, j) * 128, lane);
-    }
+    stage_l_tiles<PHASE>(L, ldl, tiles, lane, wave, blockIdx.x == 0 ? stamps : nullptr);
     PANEL_STAMP(blockIdx.x == 0 && wave == 0, 58);
     __syncthreads();
     PANEL_STAMP(blockIdx.x == 0 && wave == 0, 59);
@@ -400,10 +406,61 @@ __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_
 #undef PANEL_STAMP
 }
 
+// ---------------------------------------------------------------------------
+// vinv128: for every 128 x 128 diagonal block of a fused factor, V = L_kk^-1, stored TRANSPOSED in the block's
+// upper triangle (G[c][r] = V[r][c], r > c) -- the convention of the 16 x 16 diagonal tiles (W_jj^T strictly above
+// the diagonal, diag(V) = 1 / diag(L) implied) carried to the whole block: the strict block-upper tiles are storage
+// nothing else reads.  One workgroup per block; wave w takes tile rows w and 4 + w of the identity through the
+// trsm128 recurrence (I L^-T = V^T), skipping the column tiles left of its own (they stay zero).
+// The backward solve (solve.hip) then gets x_k = V^T r_k as a matrix-vector product instead of 8 dependent
+// 16 x 16 solve-and-update rounds.  Only ever used for vectors (alpha); the factorisation itself and the
+// predictive solves keep to 16 x 16 inverses.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void vinv128_kernel(double* A, int64_t ld) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    d2* tiles = reinterpret_cast<d2*>(smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* Lb = A + (int64_t)blockIdx.x * PB * (ld + 1);
+    stage_l_tiles<-1>(Lb, ld, tiles, lane, wave, nullptr);
+    __syncthreads();
+    for (int p = 0; p < 2; ++p) {
+        const int i = 4 * p + wave;
+        double xt[NT][4];
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xt[k][v] = (k == i && (lane & 15) == kap(lane >> 4, v)) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j >= i) {
+                double a[4], z[4] = {0., 0., 0., 0.};
+                load_afrag(tiles + trsm_slot<-1>(j, j) * 128, lane, a);
+                tile_mma(a, xt[j], z);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xt[j][v] = z[v];
+#pragma unroll
+                for (int k = j + 1; k < NT; ++k) {
+                    double b[4];
+                    load_afrag(tiles + trsm_slot<-1>(k, j) * 128, lane, b);
+                    tile_mma(b, xt[j], xt[k]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 1; k < NT; ++k)
+            if (k > i) store_xtile(Lb + (int64_t)(16 * i) * ld + 16 * k, ld, lane, xt[k]);
+    }
+}
+
 static hipError_t panel_mfma_attrs() {
     static PerDeviceOnce once;
     return once.run([]() -> hipError_t {
-        return hipFuncSetAttribute((const void*)trsm128_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)trsm128_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           NTILES * TILE_BYTES);
+        if (e != hipSuccess) return e;
+        return hipFuncSetAttribute((const void*)vinv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                    NTILES * TILE_BYTES);
     });
 }
@@ -434,6 +491,14 @@ hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X
     }
     hipLaunchKernelGGL(trsm128_kernel<-1>, dim3(grid), dim3(256), NTILES * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
                        tuning().panel_stamps);
+    return hipGetLastError();
+}
+
+hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n) {
+    if (n <= 0 || n % PB || ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15)) return hipErrorInvalidValue;
+    hipError_t e = panel_mfma_attrs();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(vinv128_kernel, dim3((unsigned)(n / PB)), dim3(256), NTILES * TILE_BYTES, s, A, ld);
     return hipGetLastError();
 }
 

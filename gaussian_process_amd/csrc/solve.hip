@@ -268,6 +268,112 @@ hipError_t launch_trsv_lt_fused(hipStream_t s, const double* L, int64_t ld, doub
     return hipGetLastError();
 }
 
+// ---- backward substitution, third generation: the diagonal blocks carry their full inverses --------------
+// After launch_vinv128 (panel_mfma.hip) the upper triangle of every 128 x 128 diagonal block G holds V^T = L_kk^-T
+// (G[c][r] = V[r][c] for r > c, the diagonal implied: 1 / G[c][c]), so the solve of a diagonal block is ONE
+// matrix-vector product,  x_k[c] = r[c] / G[c][c] + sum_{r > c} G[c][r] r[r],  instead of 8 dependent rounds.
+// Same launch structure as trsv_lt_step128_kernel (one launch per 128 unknowns, workgroup 0 updates the columns
+// next to the diagonal and then solves the next block), with two changes that shorten the chain a launch is:
+//   * every thread has all of its 64 row loads in flight at once (the second generation walked them 16 at a time:
+//     four memory round trips per launch);
+//   * workgroup 0 requests its 128 x 128 block of V^T (8 lanes per row, 16-byte pieces, 64 registers) before the
+//     update and needs no LDS copy of it: the launch uses 12 KiB of LDS instead of 135, so two workgroups fit per CU.
+constexpr int TV_LD = 9;         // partial sums per row of the block product, padded (conflict-free writes)
+
+__global__ __launch_bounds__(256) void trsv_lt_vstep_kernel(const double* __restrict__ L, int64_t ld, double* b,
+                                                             double* xout, int64_t j0, int64_t n) {
+    __shared__ __attribute__((aligned(16))) double xs[128];      // x_j
+    __shared__ __attribute__((aligned(16))) double rs[128];      // right-hand side of the next block
+    __shared__ double dinv[128];                                  // 1 / diag(L_kk)
+    __shared__ double part[256];
+    __shared__ double pv[128 * TV_LD];
+    const int tid = threadIdx.x;
+    const int64_t nchunks = (j0 + 255) / 256;
+    const int64_t chunk = nchunks - 1 - (int64_t)blockIdx.x;      // workgroup 0 takes the columns next to the diagonal
+    const bool solver = blockIdx.x == 0 && j0 >= 128;
+    const int64_t k0 = j0 - 128;                                  // first row of the next diagonal block
+    // V^T of the next block first: thread (rg = tid >> 3, q = tid & 7) holds, of rows rg + 32 p, the column pairs
+    // 2 q + 16 i; the latency hides behind the update below
+    const int rg = tid >> 3, q = tid & 7;
+    d2 g[4][8];
+    double dg = 1.0;
+    if (solver) {
+        const double* G = L + k0 * ld + k0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                g[p][i] = *reinterpret_cast<const d2*>(G + (int64_t)(rg + 32 * p) * ld + 2 * q + 16 * i);
+        if (tid < 128) dg = G[(int64_t)tid * ld + tid];
+    }
+    if (j0 < n) {
+        if (tid < 128) xs[tid] = xout[j0 + tid];
+        __syncthreads();
+        const int64_t c = chunk * 256 + 2 * (tid & 127);
+        const int half = tid >> 7;
+        double a0 = 0., a1 = 0.;
+        if (c < j0) {
+            // all 64 row loads of a thread are issued before the first is used (hoisting them above the wait for
+            // x_j as well was measured slower: the registers no longer fit without accumulation-register moves)
+            const double* col = L + (j0 + 64 * half) * ld + c;
+            const double* xh = xs + 64 * half;
+            d2 v[64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) v[r] = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                a0 = fma(v[r].x, xh[r], a0);
+                a1 = fma(v[r].y, xh[r], a1);
+            }
+        }
+        if (half) { part[2 * (tid & 127)] = a0; part[2 * (tid & 127) + 1] = a1; }
+        __syncthreads();
+        if (!half && c < j0) {
+            const d2 bv = *reinterpret_cast<const d2*>(b + c);
+            const d2 nv = d2{bv.x - (a0 + part[2 * tid]), bv.y - (a1 + part[2 * tid + 1])};
+            *reinterpret_cast<d2*>(b + c) = nv;
+            if (solver && c >= k0) { rs[c - k0] = nv.x; rs[c - k0 + 1] = nv.y; }
+        }
+    } else if (solver && tid < 128) {
+        rs[tid] = b[k0 + tid];
+    }
+    if (!solver) return;
+    if (tid < 128) dinv[tid] = 1.0 / dg;
+    __syncthreads();
+    // ---- x_k = V^T r: 8 partial sums per row, then a fixed-order sum
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = rg + 32 * p;
+        double acc = 0.;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int col = 2 * q + 16 * i;
+            const d2 rr = *reinterpret_cast<const d2*>(rs + col);
+            acc = fma(col > c ? g[p][i].x : 0.0, rr.x, acc);
+            acc = fma(col + 1 > c ? g[p][i].y : 0.0, rr.y, acc);
+        }
+        pv[c * TV_LD + q] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        double x = rs[tid] * dinv[tid];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x += pv[tid * TV_LD + i];
+        xout[k0 + tid] = x;
+    }
+}
+
+// Solves L^T x = b for a fused factor whose 128 x 128 diagonal blocks carry their inverses (launch_vinv128 has
+// run on it; n % 128 == 0); b is destroyed, the solution lands in xout (n doubles, may not alias b).
+hipError_t launch_trsv_lt_vinv(hipStream_t s, const double* L, int64_t ld, double* b, double* xout, int64_t n) {
+    if (n <= 0 || n % 128 || ld % 2) return hipErrorInvalidValue;
+    for (int64_t j0 = n; j0 >= 128; j0 -= 128) {
+        const unsigned blocks = (j0 == n) ? 1u : (unsigned)((j0 + 255) / 256);     // the first launch only solves
+        hipLaunchKernelGGL(trsv_lt_vstep_kernel, dim3(blocks), dim3(256), 0, s, L, ld, b, xout, j0, n);
+    }
+    return hipGetLastError();
+}
+
 // ---- y = A^T x for a row-major nrows x ncols block (distributed backward solve) -----------
 // grid (column chunks, row chunks of 64); partial sums per row chunk, then a fixed-order sum
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* A, int64_t ld, int64_t nrows,

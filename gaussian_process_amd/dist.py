@@ -129,12 +129,14 @@ class HipBlockOps:
                                        A.shape[0] if A is not None else 0, y.shape[0],
                                        self._p(x) if x is not None else None, self._p(y), self._p(scratch)))
 
-    def trsv_lt(self, L, b):
-        """L^T x = b, x overwrites b (L as potrf_block leaves it)"""
+    def trsv_lt(self, L, b, inverted=False):
+        """L^T x = b, x overwrites b (L as potrf_block leaves it).  The first call on a factored block writes the
+        inverses of its 128 x 128 diagonal blocks into their upper triangles; inverted=True says they are there."""
         n = b.shape[0]
         if n % 128 == 0:
             x = torch.empty_like(b)
-            check(self.lib.gpmi_dev_trsv_lt_fused(self._stream(), self._p(L), self._ld(L), self._p(b), self._p(x), n))
+            check(self.lib.gpmi_dev_trsv_lt_vinv(self._stream(), self._p(L), self._ld(L), self._p(b), self._p(x), n,
+                                                 0 if inverted else 1))
             b.copy_(x)
             return
         check(self.lib.gpmi_dev_trsv_lt(self._stream(), self._p(L), self._ld(L), self._p(b), n))
@@ -179,6 +181,7 @@ class DistGP:
         # rest of panel k is gathered, so the latency-bound potrf leaves the collective chain
         self.lookahead = int(lookahead)
         self.have_factor = False
+        self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
         self.have_test = False
         self.stage_ms = {}
 
@@ -521,6 +524,7 @@ class DistGP:
         self.sigma, self.ell = float(sigma), float(ell)
         self.have_factor = False
         self.have_v = False
+        self._vinv_blocks = set()
         self.info.fill_(INT64_MAX)
         # K + sI: my row blocks, lower part
         for li, b in enumerate(self.my_blocks):
@@ -836,7 +840,8 @@ class DistGP:
                 # one reduction kernel over the G contributions (a fixed tree for a given G and nb: the same
                 # bits on every run), not G tiny launches on the latency chain of the block
                 rhs.sub_(allp.view(G, NB).sum(dim=0))
-                ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs)
+                ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs, inverted=li in self._vinv_blocks)
+                self._vinv_blocks.add(li)
                 aloc[li * NB:(li + 1) * NB].copy_(rhs)
         # assemble the full vector in natural block order
         cmax = max(self._nblocks(r) for r in range(G))

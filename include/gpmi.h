@@ -269,6 +269,11 @@ int gpmi_dev_trsv_lt(void* stream, const double* L_dev, int64_t ld, double* b_de
 /* the same for a block as gpmi_dev_potrf_block leaves it (inverses in its diagonal tiles), n % 128 == 0: 128 unknowns
  * per launch; b_dev is destroyed, the solution goes to x_dev (n doubles, must not alias b_dev) */
 int gpmi_dev_trsv_lt_fused(void* stream, const double* L_dev, int64_t ld, double* b_dev, double* x_dev, int64_t n);
+/* the same through the inverted 128 x 128 diagonal blocks: invert != 0 first writes L_kk^-T of every 128 x 128 diagonal
+ * block into that block's upper triangle (storage nothing else reads; one launch), then -- and on every later call with
+ * invert == 0 on the same factored block -- each step is one matrix-vector product with it.  a5 of the multi-rank driver
+ * (GP_regression.py:140). */
+int gpmi_dev_trsv_lt_vinv(void* stream, double* L_dev, int64_t ld, double* b_dev, double* x_dev, int64_t n, int invert);
 /* on != 0: the block primitives called from this thread run beside a trailing update on another stream (lookahead)
  * and use their small-LDS forms, which fit on a CU next to an update workgroup; same results.  0 switches back. */
 int gpmi_dev_set_concurrent(int on);

@@ -119,7 +119,7 @@ class NumpyBlockOps:
     def gemv_t(self, A, x, y, scratch):
         self._a(y)[:] = self._a(A).T @ self._a(x) if A is not None else 0.0
 
-    def trsv_lt(self, L, b):
+    def trsv_lt(self, L, b, inverted=False):
         bb = self._a(b)
         bb[:] = sla.solve_triangular(np.tril(self._a(L)), bb, lower=True, trans='T', check_finite=False)
 

@@ -838,3 +838,34 @@ def test_ragged_sizes_across_the_lookahead_threshold(ctx, oracle, N, d, n, ell, 
     assert np.max(np.abs(var - ref["var"])) <= VAR_ATOL
     assert abs(lml - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
     assert relmax(ctx.alpha(), ref["alpha"]) <= ALPHA_RTOL
+
+
+@pytest.mark.parametrize("N", [129, 1000, 3001, 13000])
+def test_backward_solve_with_inverted_diagonal_blocks(ctx, oracle, N):
+    """a5 (GP_regression.py:140): the backward solve through the inverted 128 x 128 diagonal blocks (option
+    trsv_vinv, the default) against the 16 x 16 rounds and the oracle; the inverses live in the upper triangles of the
+    diagonal blocks of the resident factor: the factor's lower triangle, the predictive solves and the LML gradient
+    that run after alpha() must not see them"""
+    X, y, Xs = oracle.synthetic_problem(N, 4, 50, seed=7 * N)
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 1.2, 5e-4)
+    ctx.fit(X, y, 1.0, 1.2, 5e-4)
+    lo = max(0, N - 300)
+    L0 = ctx.factor(lo, N, lo, N)
+    mu0, var0 = ctx.predict(Xs, want_sd=False)
+    g0 = ctx.lml_grad()
+    ctx.set_option("trsv_vinv", 0)
+    try:
+        a_rounds = ctx.alpha()
+    finally:
+        ctx.set_option("trsv_vinv", 1)
+    a1 = ctx.alpha()
+    a2 = ctx.alpha()                      # the second call finds the inverses in place
+    assert np.array_equal(a1, a2)
+    assert relmax(a1, a_rounds) <= 1e-12
+    assert relmax(a1, ref["alpha"]) <= ALPHA_RTOL
+    assert np.array_equal(ctx.factor(lo, N, lo, N), L0)
+    assert np.array_equal(np.triu(L0, 1), np.zeros_like(L0))
+    mu1, var1 = ctx.predict(Xs, want_sd=False)
+    assert np.array_equal(mu0, mu1) and np.array_equal(var0, var1)
+    g1 = ctx.lml_grad()
+    assert np.allclose(g0, g1, rtol=1e-12, atol=0)
