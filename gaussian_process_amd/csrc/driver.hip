@@ -309,7 +309,7 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri)
     // small-LDS panel forms beside the update only for sweeps with enough rows to keep the chip busy: for a few
     // hundred test points the chain of launches is what counts, and the one-launch trsm128 is shorter
     // (N = 16384, n = 1024: 7.96 against 8.47 ms)
-    GemmShallowScope shallow(la && m >= 2048);
+    GemmShallowScope shallow(la && m >= 2048, la);
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;
     auto update = [&](int64_t c0, int64_t k, int64_t nb, int64_t ncol_upd) -> hipError_t {
         GemmArgs g;   // V[:, c0..c0+ncol_upd) -= V[:, k..k+nb) * L[c0.., k..k+nb)^T

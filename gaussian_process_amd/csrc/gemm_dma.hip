@@ -25,6 +25,8 @@
 #include <cstdlib>
 
 #include "gpmi_internal.h"
+#include <atomic>
+#include <mutex>
 
 namespace gpmi {
 
@@ -33,6 +35,7 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define GPMI_LDS __attribute__((address_space(3)))
 #define GPMI_GLB __attribute__((address_space(1)))
+#define GPMI_CONST __attribute__((address_space(4)))
 
 constexpr int DMA_MAX_SM = 128;   // supertile rows a staircase launch can describe (M up to 131072 at S = 8)
 
@@ -55,10 +58,22 @@ struct GemmDmaDev {
     int sprefix[DMA_MAX_SM + 1];
     unsigned long long* stamps;   // diagnostic build only (dbg & 16): per-tile phase clocks
     int dbg;   // timing-only ablations (probe instantiation): 1 no DMA in the loop, 2 no barrier/waits, 8 no epilogue
+    // persistent form: work counters of this launch (one per XCD) and the number of virtual blocks
+    struct PersistSlot* slot;
+    int nblocks;
 };
 
-__device__ __forceinline__ bool dma_map_tile(const GemmDmaDev& p, int& ti, int& tj) {
-    const int b = blockIdx.x;
+// Work counters of one persistent launch: workgroups on XCD x draw block numbers 8 w + x from ctr[x]; the last
+// workgroup to finish puts the slot back to zero, so a slot is ready for the launch that draws it next.
+struct PersistSlot {
+    unsigned ctr[8];
+    unsigned done;
+    unsigned pad[7];
+};
+
+// PT: GemmDmaDev, in the generic or in the constant (kernel argument) address space
+template <class PT>
+__device__ __forceinline__ bool dma_block_to_tile(const PT& p, int b, int& ti, int& tj) {
     const int xcd = b & 7;
     const int w = b >> 3;
     const int S2 = p.S * p.S;
@@ -90,7 +105,24 @@ __device__ __forceinline__ bool dma_map_tile(const GemmDmaDev& p, int& ti, int& 
     return ti < p.Tm && tj < p.Tn;
 }
 
+__device__ __forceinline__ bool dma_map_tile(const GemmDmaDev& p, int& ti, int& tj) {
+    return dma_block_to_tile(p, blockIdx.x, ti, tj);
+}
+
 constexpr int DMA_TM = 128, DMA_TN = 128;
+// a tile the mode of the launch leaves untouched (above the diagonal, right of its row band)
+template <class PT>
+__device__ __forceinline__ bool dma_tile_live(const PT& p, int ti, int tj) {
+    if (p.lower) {
+        const int64_t min_col = (int64_t)tj * DMA_TN;
+        const int64_t max_row = (int64_t)ti * DMA_TM + DMA_TM - 1;
+        if (min_col > max_row + p.diag_off) return false;
+    }
+    if (p.row_ncols) {
+        if ((int64_t)tj * DMA_TN >= p.row_ncols[ti / p.row_block_tiles]) return false;
+    }
+    return true;
+}
 constexpr int DMA_STAGE_SLOTS = (DMA_TM + DMA_TN) * 8;     // 16-byte slots per stage (A then B)
 constexpr int DMA_STAGES = 3;
 
@@ -329,6 +361,296 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
 }
 
 // ---------------------------------------------------------------------------
+// Persistent form of the 8-wave kernel: the K loops of consecutive tiles form ONE stream.
+//
+// A workgroup of the kernel above spends, per tile, ~2.5k cycles filling the ring before the first MFMA and ~14k
+// cycles after the last one on the read-modify-write of C (one exposed memory round trip under load, then the
+// stores): 2.8 % of a tile at K = 2048, 5.6 % at K = 1024, 11 % at K = 512 -- with one workgroup per CU (96 KiB
+// of LDS) nothing else covers it.  Here gridDim.x = #CUs workgroups stay resident and draw tiles from a counter:
+//   * the LDS-DMA of the NEXT tile's first two K steps is issued during the last two steps of the current tile
+//     (the ring never drains, the first MFMA of a tile follows the last of its predecessor);
+//   * the C tile is requested three steps before the end into registers that are free in the loop, so the
+//     epilogue is 32 subtractions and 32 stores;
+//   * tiles are drawn per XCD (block number 8 w + x on XCD x, w from an atomic counter) in the order the hardware
+//     would have dispatched them: the supertile -> XCD map and its L2 reuse are unchanged, and a CU that shares its
+//     cycles with a panel kernel (lookahead) simply draws fewer tiles.
+// The next block number is fetched inside the loop (atomic by wave 0, mailbox in LDS, three K steps per attempt); a
+// workgroup that reaches the end of a tile without a resolved successor drains, resolves one synchronously and
+// starts over with a prologue.  vmcnt bookkeeping: the memory counter retires in order, so a wait for "the DMA of
+// step c + 1" also waits for everything issued before it -- the C loads sit between the DMA of steps nch - 1 and
+// nch, which gives them two K steps to land.
+// ---------------------------------------------------------------------------
+template <int DUMMY>
+__device__ __forceinline__ void gemm_nt_dma_persist_body(const GemmDmaDev& p) {
+    constexpr int MI = 2, DPW = 4, RPW = 16, NFR = 6, NT = 8, NSLOT = 4;
+    constexpr int RING = DMA_STAGES * DMA_STAGE_SLOTS * 16;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    volatile GPMI_LDS int* mbox = (volatile GPMI_LDS int*)(smem_raw + RING);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = (wave >> 1) * (16 * MI);
+    const int wc = (wave & 1) * 64;
+    const int fr = lane & 15;
+    const int fg = lane >> 4;
+    const int drow = lane >> 3;
+    const int dkp = (lane & 7) ^ (drow & 7);
+    const int xcd = blockIdx.x & 7;
+    const int nch = p.nchunks;
+    const int64_t ldc = p.ldc;
+    GPMI_LDS char* lds = (GPMI_LDS char*)smem_raw;
+    const int a_dst = (RPW * wave) * 128;
+    const int b_dst = DMA_TM * 128 + (RPW * wave) * 128;
+    const unsigned c_lane = (unsigned)((fg * ldc + fr) * 8);       // byte offset of this lane inside a 16 x 16 C fragment
+
+    // the launch parameters as the kernel received them (its only argument), behind a pointer the optimiser cannot
+    // see through: they are wanted once per tile, and hoisted out of the K loop they would occupy two dozen scalar
+    // registers for its whole length
+    auto kernarg = [&]() -> const GPMI_CONST GemmDmaDev* {
+        const GPMI_CONST GemmDmaDev* pp = (const GPMI_CONST GemmDmaDev*)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(pp));
+        return pp;
+    };
+    // a wave-uniform pointer that the compiler holds in vector registers -> scalar registers
+    auto uniform_ptr = [](const void* q) -> uintptr_t {
+        const uintptr_t u = reinterpret_cast<uintptr_t>(q);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu));
+        const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32));
+        return ((uintptr_t)hi << 32) | lo;
+    };
+    // A tile as the loop wants it: the four DMA source pointers of this lane (its 8-row pieces of the A rows and of
+    // the B rows of the tile, K step 0) and the wave-uniform base of this wave's part of the C tile
+    struct TileRef { const double* d[DPW]; GPMI_GLB char* c; };
+    // block number w of this XCD -> tile; false: nothing to do for it
+    auto resolve = [&](unsigned w, TileRef& t) -> bool {
+        const GPMI_CONST GemmDmaDev* pp = kernarg();
+        int ti, tj;
+        if (!dma_block_to_tile(*pp, (int)(w * 8u + (unsigned)xcd), ti, tj)) return false;
+        if (!dma_tile_live(*pp, ti, tj)) return false;
+        // wave-uniform, but the map goes through a float square root (vector unit): back to scalar registers
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        tj = __builtin_amdgcn_readfirstlane(tj);
+        t.d[0] = pp->A + ((int64_t)ti * DMA_TM + RPW * wave + drow) * pp->lda + dkp * 2;
+        t.d[1] = t.d[0] + 8 * pp->lda;
+        int64_t b_row0 = (int64_t)tj * DMA_TN * pp->ldb;
+        if (pp->b_block_off) {
+            const int blk = tj / pp->b_block_tiles;
+            b_row0 = pp->b_block_off[blk] + (int64_t)(tj - blk * pp->b_block_tiles) * DMA_TN * pp->ldb;
+        }
+        t.d[2] = pp->B + b_row0 + (int64_t)(RPW * wave + drow) * pp->ldb + dkp * 2;
+        t.d[3] = t.d[2] + 8 * pp->ldb;
+        double* tc = pp->C + ((int64_t)ti * DMA_TM + wr) * pp->ldc + (int64_t)tj * DMA_TN + wc;
+        t.c = (GPMI_GLB char*)uniform_ptr(tc);
+        return true;
+    };
+    auto draw = [&]() -> unsigned {                 // one lane of the workgroup
+        const GPMI_CONST GemmDmaDev* pp = kernarg();
+        return atomicAdd(&pp->slot->ctr[xcd], 1u);
+    };
+    auto past_end = [&](unsigned w) -> bool {
+        const GPMI_CONST GemmDmaDev* pp = kernarg();
+        return w >= ((unsigned)pp->nblocks >> 3);
+    };
+    // a wave-uniform flag the compiler computed with vector compares -> a scalar one (scalar branches in the loop)
+    auto scalar_flag = [](bool f) -> bool { return __builtin_amdgcn_readfirstlane(f ? 1 : 0) != 0; };
+    // synchronous draw (start of the kernel, after a drain): false when the XCD's blocks are used up
+    auto draw_sync = [&](TileRef& t) -> bool {
+        for (;;) {
+            if (tid == 0) mbox[0] = (int)draw();
+            __syncthreads();
+            const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(mbox[0]);
+            __syncthreads();
+            if (scalar_flag(past_end(w))) return false;
+            if (scalar_flag(resolve(w, t))) return true;
+        }
+    };
+    // DMA wave-instruction q (0..1: A rows, 2..3: B rows) of the K step at element offset k0 into ring stage st
+    auto dma_one = [&](const double* const (&d)[DPW], int k0, int st, int q) {
+        GPMI_LDS char* base = lds + st * (DMA_STAGE_SLOTS * 16);
+        const int dst = (q < DPW / 2) ? a_dst + q * 1024 : b_dst + (q - DPW / 2) * 1024;
+        __builtin_amdgcn_global_load_lds((const GPMI_GLB void*)(d[q] + k0), (GPMI_LDS void*)(base + dst), 16, 0, 0);
+    };
+    // element (16 i + 4 v + fg, 16 j + fr) of this wave's part of the C tile; the row pitch goes through a laundered
+    // copy so that the 32 address computations stay where they are used (hoisted, they are 16 scalar registers)
+    auto c_addr = [&](GPMI_GLB char* tc, int i, int j, int v) -> GPMI_GLB double* {
+        int64_t pitch = ldc;
+        asm volatile("" : "+s"(pitch));
+        GPMI_GLB char* base = tc + ((int64_t)(16 * i + 4 * v) * pitch + 16 * j) * 8;
+        return (GPMI_GLB double*)(base + c_lane);
+    };
+    const int x7 = fr & 7;
+    const int sl0 = fr * 8 + (fg ^ x7);
+    const int sl1 = fr * 8 + ((4 + fg) ^ x7);
+    const d2* smem = reinterpret_cast<const d2*>(smem_raw);
+    auto read_one = [&](int st, int half, int q, d2 (&fa)[MI], d2 (&fb)[4]) {
+        const d2* sa = smem + st * DMA_STAGE_SLOTS;
+        const d2* sb = sa + DMA_TM * 8;
+        const int sl = half ? sl1 : sl0;
+        if (q < MI) fa[q] = sa[(wr + 16 * q) * 8 + sl];
+        else fb[q - MI] = sb[(wc + 16 * (q - MI)) * 8 + sl];
+    };
+
+#define GPMI_MFMA_X(FA, FB, T) acc[(T) >> 2][(T) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[(T) >> 2].x, FB[(T) & 3].x, acc[(T) >> 2][(T) & 3], 0, 0, 0)
+#define GPMI_MFMA_Y(FA, FB, T) acc[(T) >> 2][(T) & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[(T) >> 2].y, FB[(T) & 3].y, acc[(T) >> 2][(T) & 3], 0, 0, 0)
+#define GPMI_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    TileRef nxt;                                    // the tile resolved last
+    const double* dsrc[DPW];                        // the DMA stream's pointers: two K steps ahead of the matrix pipe
+    bool have_cur = draw_sync(nxt);
+    bool exhausted = !have_cur;
+    while (have_cur) {
+        // ---- prologue of a stream: steps 0 and 1 of the tile in flight, step 0 landed and published, F0 loaded
+        int s0 = 0, s1 = 1, s2 = 2;                 // ring stages of steps g, g + 1, g + 2
+#pragma unroll
+        for (int q = 0; q < DPW; ++q) dsrc[q] = nxt.d[q];
+#pragma unroll
+        for (int q = 0; q < DPW; ++q) dma_one(dsrc, 0, 0, q);
+#pragma unroll
+        for (int q = 0; q < DPW; ++q) dma_one(dsrc, 16, 1, q);
+        int dk = 32;                                // K offset of the DMA stream's next step
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        d2 fa0[MI], fb0[4], fa1[MI], fb1[4];
+#pragma unroll
+        for (int q = 0; q < NFR; ++q) read_one(0, 0, q, fa0, fb0);
+
+        bool stream = true;
+        while (stream) {                            // one tile per pass
+            GPMI_GLB char* c_cur = nxt.c;
+            d4 acc[MI][4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = d4{0., 0., 0., 0.};
+            double cv[MI][4][4];
+            bool have_nxt = false;
+            int fw = 0;                             // wave 0, lane 0: the block number drawn for the successor
+            const int cpre = nch - 3;               // step whose last quarter requests the C tile
+            const int last_draw = nch - 6;          // no draw is started later: its answer is read two steps on
+            for (int c = 0; c < nch; ++c) {
+                const bool in2 = c + 2 < nch, in1 = c + 1 < nch;
+                const bool more2 = in2 || have_nxt;
+                const bool more1 = in1 || have_nxt;
+                if (c + 2 == nch && have_nxt) {     // the DMA stream moves on to the successor
+#pragma unroll
+                    for (int q = 0; q < DPW; ++q) dsrc[q] = nxt.d[q];
+                    dk = 0;
+                }
+                // quarter 0 (F0 .x): fragment reads F1 <- stage of step c, k-pairs 4..7
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    GPMI_MFMA_X(fa0, fb0, 2 * q);
+                    GPMI_MFMA_X(fa0, fb0, 2 * q + 1);
+                    GPMI_FENCE();
+                    read_one(s0, 1, q, fa1, fb1);
+                    if (q + NSLOT < NFR) read_one(s0, 1, q + NSLOT, fa1, fb1);
+                    GPMI_FENCE();
+                }
+                // quarter 1 (F0 .y): the DMA of step c + 2 -- of this tile, or of the successor's first steps
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    GPMI_MFMA_Y(fa0, fb0, 2 * q);
+                    GPMI_MFMA_Y(fa0, fb0, 2 * q + 1);
+                    GPMI_FENCE();
+                    if (more2) dma_one(dsrc, dk, s2, q);
+                    GPMI_FENCE();
+                }
+                dk += 16;
+                // the DMA of step c + 1 has landed (everything older than the newest DPW wave-instructions, or than
+                // those and the 32 C loads behind it), the fragment reads of this step are in registers
+                // (one test on the path every step but three of a tile takes: all waves arrive here together, and
+                // what they execute between the last MFMA of quarter 1 and the barrier is matrix-pipe idle time)
+                if (__builtin_expect(more2 && c != cpre + 1, 1)) {
+                    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                } else if (c == cpre + 1) {
+                    if (more2) asm volatile("s_waitcnt vmcnt(36)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(32)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                GPMI_FENCE();
+                // quarter 2 (F1 .x): fragment reads F0 <- stage of step c + 1, k-pairs 0..3
+#pragma unroll
+                for (int q = 0; q < NSLOT; ++q) {
+                    GPMI_MFMA_X(fa1, fb1, 2 * q);
+                    GPMI_MFMA_X(fa1, fb1, 2 * q + 1);
+                    GPMI_FENCE();
+                    if (more1) {
+                        read_one(s1, 0, q, fa0, fb0);
+                        if (q + NSLOT < NFR) read_one(s1, 0, q + NSLOT, fa0, fb0);
+                    }
+                    GPMI_FENCE();
+                }
+                // quarter 3 (F1 .y): matrix pipe only; behind it, on step nch - 3, the request of the C tile
+#pragma unroll
+                for (int t = 0; t < NT; ++t) GPMI_MFMA_Y(fa1, fb1, t);
+                GPMI_FENCE();
+                // (one copy of every MFMA: with the quarter duplicated for this step the register allocator starts
+                // copying the accumulators around; the 32 loads in one burst cost the pipe ~300 cycles once per tile)
+                if (__builtin_expect(c == cpre, 0)) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) cv[t >> 2][t & 3][v] = *c_addr(c_cur, t >> 2, t & 3, v);
+                }
+                GPMI_FENCE();
+                // the draw of the successor: atomic, mailbox, resolve on three consecutive steps
+                if (__builtin_expect(!have_nxt && !exhausted && c >= 1 && c <= last_draw + 2, 0)) {
+                    const int ph = (c - 1) % 3;
+                    if (ph == 0 && c <= last_draw) {
+                        if (tid == 0) fw = (int)draw();
+                    } else if (ph == 1 && c <= last_draw + 1) {
+                        if (tid == 0) mbox[0] = fw;
+                    } else if (ph == 2) {
+                        const unsigned w = (unsigned)__builtin_amdgcn_readfirstlane(mbox[0]);
+                        if (scalar_flag(past_end(w))) exhausted = true;
+                        else have_nxt = scalar_flag(resolve(w, nxt));
+                    }
+                }
+                GPMI_FENCE();
+                const int t3 = s0; s0 = s1; s1 = s2; s2 = t3;
+            }
+            // ---- epilogue: C -= acc from the registers the C tile was requested into
+            if (have_nxt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) *c_addr(c_cur, i, j, v) = cv[i][j][v] - acc[i][j][v];
+            stream = have_nxt;
+        }
+        have_cur = exhausted ? false : draw_sync(nxt);
+        if (!have_cur) exhausted = true;
+    }
+#undef GPMI_MFMA_X
+#undef GPMI_MFMA_Y
+#undef GPMI_FENCE
+    // the last workgroup out puts the counters back
+    if (tid == 0) {
+        __threadfence();
+        PersistSlot* slot = kernarg()->slot;
+        const unsigned old = atomicAdd(&slot->done, 1u);
+        if (old == gridDim.x - 1) {
+#pragma unroll
+            for (int x = 0; x < 8; ++x) slot->ctr[x] = 0;
+            slot->done = 0;
+            __threadfence();
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_nt_dma_persist_kernel(const GemmDmaDev p) {
+    gemm_nt_dma_persist_body<0>(p);
+}
+// the same code under the trailing update's own symbol (GemmArgs::role == 1), as for the kernel above
+__global__ __launch_bounds__(512, 2) void chol_trailing_update_persist_kernel(const GemmDmaDev p) {
+    gemm_nt_dma_persist_body<1>(p);
+}
+
+// ---------------------------------------------------------------------------
 // Small launches (panel-internal updates, diagonal blocks, small problems: fewer 64 x 64 tiles than the chip has
 // room for): what they cost is the memory latency of every K step, not arithmetic -- the first-generation kernel
 // took ~2 us per K step of 16 because only one step was in flight.  Same LDS image and fragment maps as above,
@@ -343,12 +665,15 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
 constexpr int SM_T = 64;                                   // tile edge
 constexpr int SM_STAGE_SLOTS = (SM_T + SM_T) * 8;          // 16-byte slots per stage (A then B): 16 KiB
 static thread_local int t_small_shallow = 0;
-GemmShallowScope::GemmShallowScope(bool on) : prev(t_small_shallow) {
+static thread_local int t_two_streams = 0;
+GemmShallowScope::GemmShallowScope(bool on, bool two_streams) : prev(t_small_shallow), prev_two(t_two_streams) {
     static const int mode = getenv("GPMI_SHALLOW") ? atoi(getenv("GPMI_SHALLOW")) : 1;     // measurement only
     if (on && mode) t_small_shallow = 1;
+    if (on || two_streams) t_two_streams = 1;
 }
-GemmShallowScope::~GemmShallowScope() { t_small_shallow = prev; }
+GemmShallowScope::~GemmShallowScope() { t_small_shallow = prev; t_two_streams = prev_two; }
 bool gemm_shallow_active() { return t_small_shallow != 0; }
+bool gemm_two_streams_active() { return t_two_streams != 0; }
 
 struct GemmSmallDev {
     double* C;
@@ -476,6 +801,41 @@ hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a) {
     return hipGetLastError();
 }
 
+// Counter slots of the persistent launches, one pool per device: a launch takes the next slot of a ring (two launches
+// that run at the same time on different streams never share one), a slot is zero when it is handed out (allocated
+// zeroed, put back to zero by the last workgroup of the launch that used it).
+struct PersistPool {
+    static constexpr int SLOTS = 16384;
+    PersistSlot* base = nullptr;
+    int groups = 0;                  // workgroups of a persistent launch: one per CU, a multiple of the 8 XCDs
+    std::atomic<unsigned> head{0};
+    PersistSlot* next() { return base + (head.fetch_add(1, std::memory_order_relaxed) % SLOTS); }
+};
+
+static PersistPool* persist_pool() {
+    static std::mutex mu;
+    static PersistPool pools[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    PersistPool& pl = pools[dev];
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pl.base) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        void* q = nullptr;
+        if (hipMalloc(&q, sizeof(PersistSlot) * PersistPool::SLOTS) != hipSuccess) return nullptr;
+        if (hipMemset(q, 0, sizeof(PersistSlot) * PersistPool::SLOTS) != hipSuccess) { (void)hipFree(q); return nullptr; }
+        pl.groups = (prop.multiProcessorCount / 8) * 8;
+        if (pl.groups < 8) { (void)hipFree(q); return nullptr; }
+        const void* fns[] = {(const void*)gemm_nt_dma_persist_kernel, (const void*)chol_trailing_update_persist_kernel};
+        for (const void* f : fns)
+            if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(DMA_STAGES * DMA_STAGE_SLOTS * 16 + 16)) != hipSuccess) { (void)hipFree(q); return nullptr; }
+        pl.base = static_cast<PersistSlot*>(q);
+    }
+    return &pl;
+}
+
 bool gemm_dma_eligible(const GemmArgs& a) {
     return a.mode == 0 && a.N % 128 == 0 && a.M % 128 == 0 && a.K % 16 == 0 && a.K >= 32;
 }
@@ -540,6 +900,23 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     const Tuning& tn = tuning();
     p.dbg = tn.gemm_dbg & 0xff;
     p.stamps = tn.gemm_stamps;
+    p.slot = nullptr;
+    p.nblocks = nblocks;
+    // persistent form: launches with at least two rounds of tiles and a K loop long enough to draw the successor in --
+    // and the chip to themselves: resident workgroups (216 registers per lane, two waves per SIMD) leave no room on a
+    // CU for the panel kernels of the other stream, which would then wait for the whole launch instead of a tile
+    // (lookahead with both forms: N = 16384 fit + predict 39.8 against 42.9 ms)
+    if (tn.gemm_persist && tn.gemm_dma_waves == 8 && !p.dbg && p.nchunks >= 16 && !gemm_two_streams_active()) {
+        PersistPool* pool = persist_pool();
+        if (!pool) return hipErrorOutOfMemory;
+        if (nblocks >= 2 * pool->groups) {
+            p.slot = pool->next();
+            constexpr size_t ldsp = lds + 16;          // ring + mailbox
+            if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);
+            else hipLaunchKernelGGL(gemm_nt_dma_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);
+            return hipGetLastError();
+        }
+    }
     if (tn.gemm_dma_waves == 8) {
         if (p.dbg) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, true>), dim3(nblocks), dim3(512), lds, s, p);
         else if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_dma_kernel, dim3(nblocks), dim3(512), lds, s, p);

@@ -106,6 +106,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->tune.trsm_wave = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_small_dma")) {
         c->tune.gemm_small_dma = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_persist")) {
+        c->tune.gemm_persist = value ? 1 : 0;
     } else if (!strcmp(name, "trsv_vinv")) {
         c->tune.trsv_vinv = value ? 1 : 0;
     } else if (!strcmp(name, "panel_fused")) {
@@ -657,6 +659,7 @@ int gpmi_lml_batch(gpmi_ctx* c, const double* triples, int64_t T, double* lml_ou
     auto work = [&](int r) {
         gpmi_ctx* l = lane[(size_t)r];
         TuneScope tune_scope(&l->tune);         // this lane's thread runs with this lane's options
+        GemmShallowScope shares_chip(false, L > 1);   // another lane's kernels run beside this one's: no launch takes the whole chip
         if (hipSetDevice(l->device) != hipSuccess) { lane_rc[(size_t)r] = GPMI_ERR_RUNTIME; lane_err[(size_t)r] = "hipSetDevice"; return; }
         for (int64_t t = r; t < T; t += L) {
             const double ell = triples[3 * t], sigma = triples[3 * t + 1], s2 = triples[3 * t + 2];

@@ -18,6 +18,7 @@ constexpr int IB = 64;      // inner (register-resident) panel width
 struct Tuning {
     int gemm_use_dma = 1;       // LDS-DMA GEMM for launches with >= 256 tiles
     int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
+    int gemm_persist = 1;       // resident workgroups that chain the K loops of consecutive tiles (launches with >= 2 rounds of tiles)
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always
     int rbf_blocks = 16384;     // persistent blocks of the register-path K build
@@ -90,10 +91,13 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a);
 // gemm_dma.hip: latency-oriented variant for launches with few tiles (64 x 64 tiles, eight K steps in flight)
 bool gemm_small_eligible(const GemmArgs& a);
 bool gemm_shallow_active();
-// while alive on this thread, small launches use the shallow ring (they run beside a trailing update)
+bool gemm_two_streams_active();
+// while alive on this thread: `on` -- small launches use the shallow ring and trsm128 its two-launch form (they run
+// beside a trailing update); `on` or `two_streams` -- the calling driver keeps two streams busy at once, so no launch
+// may take the whole chip for its whole length (the persistent GEMM form stays off)
 struct GemmShallowScope {
-    int prev;
-    explicit GemmShallowScope(bool on);
+    int prev, prev_two;
+    explicit GemmShallowScope(bool on, bool two_streams = false);
     ~GemmShallowScope();
 };
 hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a);
