@@ -667,8 +667,7 @@ constexpr int SM_STAGE_SLOTS = (SM_T + SM_T) * 8;          // 16-byte slots per 
 static thread_local int t_small_shallow = 0;
 static thread_local int t_two_streams = 0;
 GemmShallowScope::GemmShallowScope(bool on, bool two_streams) : prev(t_small_shallow), prev_two(t_two_streams) {
-    static const int mode = getenv("GPMI_SHALLOW") ? atoi(getenv("GPMI_SHALLOW")) : 1;     // measurement only
-    if (on && mode) t_small_shallow = 1;
+    if (on) t_small_shallow = 1;
     if (on || two_streams) t_two_streams = 1;
 }
 GemmShallowScope::~GemmShallowScope() { t_small_shallow = prev; t_two_streams = prev_two; }

@@ -52,9 +52,7 @@ int gpmi_ctx_create(int device, gpmi_ctx** out) {
     c->device = device;
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    int prio_main = prio_lo;
-    if (const char* pm = getenv("GPMI_MAIN_PRIO")) prio_main = atoi(pm);
-    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_main);
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo);
     if (e != hipSuccess) { delete c; return fail_runtime(e, "hipStreamCreate"); }
     e = hipStreamCreateWithPriority(&c->pstream, hipStreamNonBlocking, prio_hi);
     if (e != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return fail_runtime(e, "hipStreamCreate"); }
