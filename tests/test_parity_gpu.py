@@ -869,3 +869,27 @@ def test_backward_solve_with_inverted_diagonal_blocks(ctx, oracle, N):
     assert np.array_equal(mu0, mu1) and np.array_equal(var0, var1)
     g1 = ctx.lml_grad()
     assert np.allclose(g0, g1, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("N,n", [(6000, 700), (9000, 300)])
+def test_persistent_update_gemm_gives_the_same_bits(ctx, oracle, N, n):
+    """GP_regression.py:138-144 below the lookahead threshold: the update GEMMs run as resident workgroups that chain
+    the K loops of consecutive tiles (option gemm_persist, the default where one stream runs) -- same tiles, same
+    summation order as one workgroup per tile: LML, mean, variance, alpha and the LML gradient bit for bit"""
+    X, y, Xs = oracle.synthetic_problem(N, 6, n, seed=N + n)
+    out = []
+    for pers in (0, 1):
+        ctx.set_option("gemm_persist", pers)
+        try:
+            lml = ctx.fit(X, y, 1.0, 1.6, 5e-4)
+            mu, var = ctx.predict(Xs, want_sd=False)
+            out.append((lml, mu.copy(), var.copy(), ctx.alpha(), ctx.lml_grad()))
+        finally:
+            ctx.set_option("gemm_persist", 1)
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][3], out[1][3])
+    assert out[0][4] == out[1][4]
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 1.6, 5e-4)
+    assert abs(out[1][0] - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
+    assert np.max(np.abs(out[1][1] - ref["mu"])) <= MU_ATOL
