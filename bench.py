@@ -353,6 +353,13 @@ def main():
                 out["alpha_hbm"] = {"bound": "hbm", "achieved": abytes / (al * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS,
                                     "unit": "GB/s", "frac": abytes / (al * 1e-3) / 1e9 / PEAK_HBM_GBPS, "bytes": abytes,
                                     "ms": al, "note": "a5: backward solve L^T alpha = m reads the triangle once"}
+            sv = stage.get("solve_v", 0.0) / k
+            if sv > 0:
+                vflops = float(N) * N * n
+                out["solve_v_mfma"] = {"bound": "mfma", "achieved": vflops / (sv * 1e-3) / 1e12, "peak": PEAK_FP64_MFMA_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": vflops / (sv * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                                       "flops": vflops, "ms": sv,
+                                       "note": "a7: v = L^-1 K_s as a blocked sweep (trsm128 leaves + MFMA updates), N^2 n flop"}
             # the peaks as this box reports them (hipDeviceProp_t), next to the nominal ones the fractions are priced against
             try:
                 di = ctx.device_info()
