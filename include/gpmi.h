@@ -68,12 +68,14 @@ int gpmi_ctx_destroy(gpmi_ctx* ctx);
 /* tuning knobs; unknown names -> GPMI_ERR_BAD_ARG.
  * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
  *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "lanes" (factorisations in flight in
- *               gpmi_lml_batch, 0 = by size), "ramp" (0/1, default 0: block widths ramp up/down
- *               at the ends of the sweep when "nb" is automatic);
+ *               gpmi_lml_batch, 0 = by size), "ramp" (bit mask, default 0: 1 block widths ramp up at the start of the
+ *               sweep, 2 half width over the last blocks, 4 quarter width for the last one, when "nb" is automatic);
  *               kernel selection (for measurements; also per context -- the lanes of gpmi_lml_batch inherit them):
  *               "panel_fused" (0/1: 128-column MFMA panel kernels / first-generation 64-column leaves),
- *               "gemm_dma" (0/1), "gemm_dma_waves" (4/8), "gemm_small_tiles" (0/1), "trsm_wave" (0/1),
- *               "rbf_blocks" (persistent blocks of the K build).
+ *               "gemm_dma" (0/1), "gemm_dma_waves" (4/8), "gemm_small_tiles" (0/1), "gemm_small_dma" (0/1),
+ *               "gemm_persist" (0/1: resident workgroups for update GEMMs that have the chip to themselves),
+ *               "trsv_vinv" (0/1: backward solve through the inverted 128 x 128 diagonal blocks / 16 x 16 rounds),
+ *               "trsm_wave" (0/1), "rbf_blocks" (persistent blocks of the K build).
  * The context-free gpmi_dev_* primitives run with the defaults. */
 int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);
 
