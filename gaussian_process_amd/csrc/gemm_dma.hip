@@ -372,15 +372,17 @@ __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const 
 //   * the C tile is requested three steps before the end into registers that are free in the loop, so the
 //     epilogue is 32 subtractions and 32 stores;
 //   * tiles are drawn per XCD (block number 8 w + x on XCD x, w from an atomic counter) in the order the hardware
-//     would have dispatched them: the supertile -> XCD map and its L2 reuse are unchanged, and a CU that shares its
-//     cycles with a panel kernel (lookahead) simply draws fewer tiles.
+//     would have dispatched them: the supertile -> XCD map and its L2 reuse are unchanged, and a CU that runs
+//     behind simply draws fewer tiles.
 // The next block number is fetched inside the loop (atomic by wave 0, mailbox in LDS, three K steps per attempt); a
 // workgroup that reaches the end of a tile without a resolved successor drains, resolves one synchronously and
 // starts over with a prologue.  vmcnt bookkeeping: the memory counter retires in order, so a wait for "the DMA of
 // step c + 1" also waits for everything issued before it -- the C loads sit between the DMA of steps nch - 1 and
 // nch, which gives them two K steps to land.
+// Used for launches that have the chip to themselves (see launch_gemm_nt_dma): at 216 registers per lane and two waves per
+// SIMD nothing else fits on a CU beside a resident workgroup.  ROLE only separates the two kernel symbols.
 // ---------------------------------------------------------------------------
-template <int DUMMY>
+template <int ROLE>
 __device__ __forceinline__ void gemm_nt_dma_persist_body(const GemmDmaDev& p) {
     constexpr int MI = 2, DPW = 4, RPW = 16, NFR = 6, NT = 8, NSLOT = 4;
     constexpr int RING = DMA_STAGES * DMA_STAGE_SLOTS * 16;
