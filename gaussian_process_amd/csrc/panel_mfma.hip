@@ -134,11 +134,10 @@ __device__ __forceinline__ int factor16_packed(double (&v)[16], int lane) {
     for (int i = 0; i < RSQ_STAGES; ++i) ch.stage(i);
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const bool ok = ch.p > 0.0;
-        if (!ok && bad == 16) bad = c;
-        const double s = ok ? ch.g : __builtin_nan("");
-        const double rinv = ok ? ch.h : __builtin_nan("");
-        v[c] = (lane == c) ? s : v[c] * rinv;
+        // a pivot that is not positive needs no special case beyond its index: 1/sqrt of a negative number is NaN, of a
+        // zero +-inf and p * inf = NaN, so g and h are NaN and everything after this column is
+        if (!(ch.p > 0.0) && bad == 16) bad = c;
+        v[c] = (lane == c) ? ch.g : v[c] * ch.h;
         PANEL_FENCE();
         int st = 0;
         if (c < 15) {
