@@ -23,6 +23,7 @@
 // The A operands (W_jj, -L_kj) live in LDS as 16 rows x 128 bytes, row i' = M[rho(i')][:], 16-byte slots
 // XOR-swizzled by (i' >> 1) & 7: both ds_read_b128 of a fragment are conflict-free (brute-force checked).
 #include "gpmi_internal.h"
+#include <utility>
 
 namespace gpmi {
 
@@ -322,30 +323,115 @@ __device__ __forceinline__ constexpr int trsm_slot(int j, int k) {      // k <= 
 template <int PHASE> constexpr int trsm_tiles() { return PHASE == 0 ? 26 : PHASE == 1 ? 10 : NTILES; }
 
 // Staging of a 128 x 128 factored diagonal block as A operands (4 waves): the off-diagonal tiles of this phase,
-// negated, round-robin over the waves, then the stored inverses of the diagonal tiles.
+// negated, round-robin over the waves, and the stored inverses of the diagonal tiles.  A wave first REQUESTS all of its
+// tiles (up to seven off-diagonal ones and two diagonal ones, 36 registers) and only then publishes them: one memory
+// round trip instead of one per tile (the first form, a load-and-publish per tile under a per-wave test, took 12.4k
+// cycles of a 12 us launch).  The tile list of a phase is a compile-time table, (j << 4) | k in launch order.
+template <int PHASE> struct StageList {
+    static constexpr int J0 = PHASE == 1 ? 4 : 0, J1 = PHASE == 0 ? 4 : NT;
+    static constexpr int count() {
+        int n = 0;
+        for (int j = 1; j < NT; ++j)
+            for (int k = 0; k < j; ++k)
+                if (k >= J0 && k < J1) ++n;
+        return n;
+    }
+    static constexpr int entry(int t) {
+        int n = 0;
+        for (int j = 1; j < NT; ++j)
+            for (int k = 0; k < j; ++k)
+                if (k >= J0 && k < J1) {
+                    if (n == t) return (j << 4) | k;
+                    ++n;
+                }
+        return 0;
+    }
+};
+template <int PHASE, int... T>
+__device__ __forceinline__ int stage_entry(int t, std::integer_sequence<int, T...>) {
+    // a switch the compiler turns into a scalar table lookup: t is wave-uniform
+    constexpr int tab[] = {StageList<PHASE>::entry(T)...};
+    return tab[t];
+}
+
+template <int PHASE>
+__device__ __forceinline__ void stage_l_tiles_batched(const double* L, int64_t ldl, d2* tiles, int lane, int wave,
+                                                      unsigned long long* stamps) {
+    constexpr int J0 = StageList<PHASE>::J0, J1 = StageList<PHASE>::J1;
+    constexpr int NOFF = StageList<PHASE>::count();
+    constexpr int PER = (NOFF + 3) / 4;                 // off-diagonal tiles per wave
+    constexpr int NW = (J1 - J0 + 3) / 4;               // diagonal tiles per wave
+    const int n = lane & 15, fg = lane >> 4;
+    double x[PER][4], w[NW][4];
+    int slot[PER];
+    // ---- requests
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int t = 4 * i + wave;
+        const int e = stage_entry<PHASE>(t < NOFF ? t : NOFF - 1, std::make_integer_sequence<int, NOFF>{});
+        const int jj = e >> 4, kk = e & 15;
+        slot[i] = t < NOFF ? (PHASE == 0 ? (jj < 4 ? jj * (jj + 1) / 2 + kk : 10 + (jj - 4) * 4 + kk)
+                                         : PHASE == 1 ? (jj - 4) * (jj - 3) / 2 + (kk - 4) : jj * (jj + 1) / 2 + kk)
+                           : -1;
+        load_xtile(L + (int64_t)(16 * jj) * ldl + 16 * kk, ldl, lane, x[i]);
+    }
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const int j = J0 + wave + 4 * r;
+        const double* Ljj = L + (int64_t)(16 * (j < J1 ? j : J0)) * (ldl + 1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = kap(fg, q);
+            w[r][q] = (k <= n) ? Ljj[(int64_t)k * ldl + n] : 0.0;     // W^T above the diagonal, L's diagonal on it
+        }
+    }
+    // ---- publication
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+        if (slot[i] >= 0) publish_tile(tiles + slot[i] * 128, lane, x[i], -1.0);
+    if (stamps && wave == 0 && lane == 0) stamps[57] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int r = 0; r < NW; ++r) {
+        const int j = J0 + wave + 4 * r;
+        if (j < J1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (kap(fg, q) == n) w[r][q] = rcp_newton(w[r][q]);        // diag(W) = 1 / diag(L)
+            publish_tile(tiles + trsm_slot<PHASE>(j, j) * 128, lane, w[r], 1.0);
+        }
+    }
+}
+
+// The two-launch forms (PHASE 0 / 1) run beside a trailing update, where what counts is that two workgroups fit on a CU
+// next to an update workgroup (<= 112 registers): they keep the one-tile-at-a-time staging (108 / 68 registers against
+// 138 / 74 batched); the one-launch form, which has the CU to itself, stages batched (154 registers).
 template <int PHASE>
 __device__ __forceinline__ void stage_l_tiles(const double* L, int64_t ldl, d2* tiles, int lane, int wave,
                                               unsigned long long* stamps) {
-    constexpr int J0 = PHASE == 1 ? 4 : 0, J1 = PHASE == 0 ? 4 : NT;
-    int t = 0;
+    if constexpr (PHASE == -1) {
+        stage_l_tiles_batched<PHASE>(L, ldl, tiles, lane, wave, stamps);
+    } else {
+        constexpr int J0 = PHASE == 1 ? 4 : 0, J1 = PHASE == 0 ? 4 : NT;
+        int t = 0;
 #pragma unroll
-    for (int j = 1; j < NT; ++j)
+        for (int j = 1; j < NT; ++j)
 #pragma unroll
-        for (int k = 0; k < j; ++k) {
-            if (k >= J0 && k < J1) {
-                if ((t & 3) == wave) {
-                    double x[4];
-                    load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
-                    publish_tile(tiles + trsm_slot<PHASE>(j, k) * 128, lane, x, -1.0);
+            for (int k = 0; k < j; ++k) {
+                if (k >= J0 && k < J1) {
+                    if ((t & 3) == wave) {
+                        double x[4];
+                        load_xtile(L + (int64_t)(16 * j) * ldl + 16 * k, ldl, lane, x);
+                        publish_tile(tiles + trsm_slot<PHASE>(j, k) * 128, lane, x, -1.0);
+                    }
+                    ++t;
                 }
-                ++t;
             }
-        }
-    if (stamps && wave == 0 && lane == 0) stamps[57] = __builtin_amdgcn_s_memtime();
+        if (stamps && wave == 0 && lane == 0) stamps[57] = __builtin_amdgcn_s_memtime();
 #pragma unroll
-    for (int j = J0; j < J1; ++j)
-        if (((j - J0) & 3) == wave)
-            stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + trsm_slot<PHASE>(j, j) * 128, lane);
+        for (int j = J0; j < J1; ++j)
+            if (((j - J0) & 3) == wave)
+                stage_w_tile(L + (int64_t)(16 * j) * ldl + 16 * j, ldl, tiles + trsm_slot<PHASE>(j, j) * 128, lane);
+    }
 }
 
 template <int PHASE>
