@@ -272,7 +272,13 @@ def test_bench_two_ranks_through_the_self_spawn_path():
     assert p1.returncode == 0, p1.stderr[-3000:]
     one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
     assert abs(one["lml"] - out["lml"]) <= 1e-12 * abs(one["lml"])
-    assert "roofline" in one and "targets" in one
+    # the bench contract's keys on the single-GPU line (roofline blocks of the trailing update, a1+a2, a5, a7)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "targets", "kbuild_hbm", "alpha_hbm", "solve_v_mfma",
+                "stages_ms"):
+        assert key in one, key
+    assert one["dtype"] == "f64" and one["config"]["workload"] and one["roofline"]["bound"] == "mfma"
+    assert 0 < one["alpha_hbm"]["frac"] < 1 and 0 < one["solve_v_mfma"]["frac"] < 1
 
 
 @pytest.mark.gpu
