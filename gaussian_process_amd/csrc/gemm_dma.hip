@@ -854,7 +854,12 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     if (a.b_block_off && (a.b_block_rows <= 0 || a.b_block_rows % 128)) return hipErrorInvalidValue;
     p.tri = (a.lower && a.diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
     const bool stairs = a.row_ncols && a.row_ncols_host && a.row_bands > 0 && !a.lower;
+    // supertile edge: 8 tiles, but never wider than the launch -- a strip of Tn = 1 (a panel-internal update of 128
+    // columns) enumerated in 8 x 8 supertiles is seven dead workgroups for every live one, and a dead workgroup still has
+    // to be handed a CU with 96 KiB of free LDS before it can return (32768 x 128 x 128: 88 us, beside a trailing update
+    // each of them waits for a tile to finish)
     int S = 8;
+    while (S > 1 && (S > p.Tn || S > p.Tm)) S >>= 1;
     for (;; S >>= 1) {
         const int SM = (p.Tm + S - 1) / S, SN = (p.Tn + S - 1) / S;
         int ns = p.tri ? SM * (SM + 1) / 2 : SM * SN;

@@ -261,7 +261,7 @@ bool gemm_nt_routes_dma(const GemmArgs& a) {
     const Tuning& tn = tuning();
     if (a.b_block_off) return true;            // only the LDS-DMA kernel reads B through a block table
     return tn.gemm_use_dma && (!tn.gemm_dbg || tn.gemm_dbg >= 256) && gemm_dma_eligible(a) &&
-           (a.M / 128) * (a.N / 128) >= 256;
+           (a.M / 128) * (a.N / 128) >= 128;      // from half a round of tiles up (below: 64 x 64 tiles, launch_gemm_nt_small)
 }
 
 hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
