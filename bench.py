@@ -43,8 +43,8 @@ TARGET_KBUILD_FRAC = 0.60
 TARGET_SPEEDUP_8 = 6.0
 TARGET_MEAN_TOL = 1e-8
 # the committed rocprofv3 PMC passes `roofline.traffic` is read from (same command, N=65536 n=4096)
-TRAFFIC_PROFILE = os.path.join("profiles", "r02_roofline_traffic.json")
-TRAFFIC_PROFILE_FALLBACK = os.path.join("profiles", "r01d_roofline_traffic.json")
+TRAFFIC_PROFILE = os.path.join("profiles", "r02c_roofline_traffic.json")
+TRAFFIC_PROFILE_FALLBACK = os.path.join("profiles", "r02_roofline_traffic.json")
 
 
 def algorithmic_flops(N, n):
