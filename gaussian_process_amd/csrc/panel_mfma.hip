@@ -237,8 +237,11 @@ __device__ __forceinline__ void stage_w_tile(const double* Ljj, int64_t ldl, d2*
 //   2  waves i > j  L_ij = S_ij W_jj^T (4 MFMAs), to memory and, negated, to LDS
 //   3  waves i > j  S_ik -= L_ij L_kj^T for k = j+1..i (4 MFMAs per tile), the diagonal chain first
 // Two barriers per step; a wave's tiles never leave its registers.  LDS holds only the operands of the current
-// step (8 tile slots + W_jj + the scratch tile, 20 KiB), so the kernel fits on a CU beside a trailing-update
-// workgroup and starts at once under lookahead instead of waiting for a tile to finish.
+// step (8 tile slots + W_jj + the scratch tile, 20 KiB).  Beside a trailing update (lookahead) the workgroup still waits
+// for an empty CU -- 123 registers at two waves per SIMD do not fit next to an update workgroup's 2 x 144 -- which was
+// measured to be the better deal: a 94-register variant that does fit and starts at once runs its serial 16 x 16
+// factors so much slower on SIMDs shared with the update's MFMA stream that the panel stream gets longer (DESIGN.md
+// section 7 item 2).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, int64_t col_offset, int64_t* info,
                                                         unsigned long long* stamps) {
