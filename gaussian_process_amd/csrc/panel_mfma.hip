@@ -171,101 +171,6 @@ __device__ __forceinline__ int factor16_packed(double (&v)[16], int lane) {
     return bad;
 }
 
-// ---------------------------------------------------------------------------
-// Cholesky AND inverse of a 16 x 16 block by one wave, second form: 4 x 4 micro-blocks with every rank-4 update and
-// every "rows below" product on the matrix pipe.  Register layout ("row layout"): lane (i = lane & 15, k = lane >> 4)
-// holds X[i][4 m + k] in x[m] -- register m IS the MFMA operand (A or B alike) of column block m and, because the
-// updates are symmetric (or fed with the operands swapped), also the layout the MFMA returns its result in: a tile is
-// updated in place as the accumulator.  Micro-block b:
-//   * the 10 entries of the diagonal 4 x 4 block by v_readlane; its factor l and l^-1 = w redundantly on every lane:
-//     the pivots through an LDL^T recurrence with reciprocals (short dependent chains), then the four 1/sqrt chains
-//     side by side;
-//   * P = A[:, blk] w^T (the new columns of L below the block) and Y = V[:, blk] w^T: one MFMA each, w as a 4 x 4 operand;
-//   * A -= P P^T and V -= Y P^T (P with the rows up to the block zeroed): one MFMA each;
-//   * the block's own rows of L are the l computed on the lanes (NOT the product D w^T, a cancellation that costs
-//     seven digits on ill-conditioned blocks), selected into place in the shadow of the update MFMAs.
-// V starts as the identity and ends as L^-T = W^T.  No LDS, no barrier.  Only entries on and below the diagonal of A
-// are used.  Returns the first non-positive pivot (16 if none).
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void rsq_full(double p, double& root, double& rinv) {
-    RsqChain ch;
-    ch.p = p;
-#pragma unroll
-    for (int i = 0; i < RSQ_STAGES; ++i) ch.stage(i);
-    root = ch.g; rinv = ch.h;
-}
-__device__ __forceinline__ double tri_pick(int lane, int l0, double v00, double v10, double v11, double v20, double v21,
-                                           double v22, double v30, double v31, double v32, double v33) {
-    // entry (p, k) of a lower triangular 4 x 4 matrix for the lane l0 + p + 16 k, 0 elsewhere: ten independent selects
-    // and a sum tree (at most one term is non-zero on a lane)
-    const double s0 = (lane == l0 ? v00 : 0.0) + (lane == l0 + 1 ? v10 : 0.0), s1 = (lane == l0 + 2 ? v20 : 0.0) + (lane == l0 + 3 ? v30 : 0.0);
-    const double s2 = (lane == l0 + 17 ? v11 : 0.0) + (lane == l0 + 18 ? v21 : 0.0), s3 = (lane == l0 + 19 ? v31 : 0.0) + (lane == l0 + 34 ? v22 : 0.0);
-    const double s4 = (lane == l0 + 35 ? v32 : 0.0) + (lane == l0 + 51 ? v33 : 0.0);
-    return ((s0 + s1) + (s2 + s3)) + s4;
-}
-
-__device__ __forceinline__ int factor16_mfma(d4& A4, d4& V4, int lane) {
-    const int i = lane & 15;
-    int bad = 16;
-    const d4 zero = d4{0., 0., 0., 0.};
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int base = 4 * b;
-        // diagonal block D[p][q] = A[base + p][base + q]: lane (base + p) + 16 q, register b
-        const double d00 = readlane_d(A4[b], base + 0), d10 = readlane_d(A4[b], base + 1), d20 = readlane_d(A4[b], base + 2),
-                     d30 = readlane_d(A4[b], base + 3);
-        const double d11 = readlane_d(A4[b], base + 1 + 16), d21 = readlane_d(A4[b], base + 2 + 16),
-                     d31 = readlane_d(A4[b], base + 3 + 16);
-        const double d22 = readlane_d(A4[b], base + 2 + 32), d32 = readlane_d(A4[b], base + 3 + 32);
-        const double d33 = readlane_d(A4[b], base + 3 + 48);
-        // pivots t0..t3 (Schur complements) by LDL^T with reciprocals; e_pq are the Schur entries below them
-        const double i0 = rcp_newton(d00);
-        const double m10 = d10 * i0, m20 = d20 * i0, m30 = d30 * i0;
-        const double t1 = fma(-m10, d10, d11);
-        const double e21 = fma(-m20, d10, d21), e31 = fma(-m30, d10, d31);
-        const double i1 = rcp_newton(t1);
-        const double m21 = e21 * i1, m31 = e31 * i1;
-        const double t2 = fma(-m21, e21, fma(-m20, d20, d22));
-        const double e32 = fma(-m31, e21, fma(-m30, d20, d32));
-        const double i2 = rcp_newton(t2);
-        const double m32 = e32 * i2;
-        const double t3 = fma(-m32, e32, fma(-m31, e31, fma(-m30, d30, d33)));
-        const int first_bad = !(d00 > 0.0) ? base : !(t1 > 0.0) ? base + 1 : !(t2 > 0.0) ? base + 2 : !(t3 > 0.0) ? base + 3 : 16;
-        bad = bad < first_bad ? bad : first_bad;
-        // the four 1/sqrt chains are independent now
-        double l00, r0, l11, r1, l22, r2, l33, r3;
-        rsq_full(d00, l00, r0);
-        rsq_full(t1, l11, r1);
-        rsq_full(t2, l22, r2);
-        rsq_full(t3, l33, r3);
-        const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
-        const double l21 = e21 * r1, l31 = e31 * r1;
-        const double l32 = e32 * r2;
-        const double w10 = -(l10 * r0) * r1;
-        const double w21 = -(l21 * r1) * r2;
-        const double w32 = -(l32 * r2) * r3;
-        const double w20 = -fma(l21, w10, l20 * r0) * r2;
-        const double w31 = -fma(l32, w21, l31 * r1) * r3;
-        const double w30 = -fma(l32, w20, fma(l31, w10, l30 * r0)) * r3;
-        const double wop = tri_pick(lane, 0, r0, w10, r1, w20, w21, r2, w30, w31, w32, r3);
-        const d4 Pr = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, A4[b], zero, 0, 0, 0);     // lane (i, k): P[i][k]
-        const d4 Yr = __builtin_amdgcn_mfma_f64_16x16x4f64(wop, V4[b], zero, 0, 0, 0);     // lane (i, k): Y[i][k]
-        const int p = i - base;
-        const double Pz = p >= 4 ? Pr[0] : 0.0;
-        A4[b] = Pz;
-        V4[b] = Yr[0];
-        if (b < 3) {
-            A4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pz, Pz, A4, 0, 0, 0);     // A -= P P^T (register b gets + 0)
-            V4 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pz, Yr[0], V4, 0, 0, 0);  // V -= Y P^T
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the block's own rows, behind the MFMAs
-        const double lsel = tri_pick(lane, base, l00, l10, l11, l20, l21, l22, l30, l31, l32, l33);
-        A4[b] = (p >= 0 && p < 4) ? lsel : A4[b];
-    }
-    return bad;
-}
-
 // lane 16 + c holds column c of W (v[r] = W[r][c]): write it as an A-operand tile
 __device__ __forceinline__ void publish_w(double* tile, int lane, const double (&v)[16]) {
     if (lane >= 16 && lane < 32) {
@@ -287,24 +192,24 @@ __device__ __forceinline__ void publish_w(double* tile, int lane, const double (
 __device__ __noinline__ void factor_diag_tile(const double* scratch, double* Ajj, int64_t ld, double* wtile,
                                               int64_t col0, int64_t* info) {
     const int lane = threadIdx.x & 63;
-    const int i = lane & 15, k = lane >> 4;
-    d4 A4, V4;
+    double v[16];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        A4[m] = scratch[i * SCR_LD + 4 * m + k];
-        V4[m] = (i == 4 * m + k) ? 1.0 : 0.0;
+    for (int k = 0; k < 16; k += 2) {
+        const d2 t = *reinterpret_cast<const d2*>(scratch + (lane & 15) * SCR_LD + k);
+        v[k] = (lane < 16) ? t.x : ((lane - 16 == k) ? 1.0 : 0.0);
+        v[k + 1] = (lane < 16) ? t.y : ((lane - 16 == k + 1) ? 1.0 : 0.0);
     }
-    const int bad = factor16_mfma(A4, V4, lane);
+    const int bad = factor16_packed(v, lane);
     if (bad < 16 && lane == 0) atomicMin((unsigned long long*)info, (unsigned long long)(col0 + bad));
-    // to memory: L on and below the diagonal, V = W^T strictly above it (G[i][c] = W[c][i], c > i);
-    // to LDS: W as an A operand, element (r, c) = V[c][r]
-    double* row = Ajj + (int64_t)i * ld;
+    if (lane < 32) {
+        double* row = Ajj + (int64_t)(lane & 15) * ld;
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int c = 4 * m + k;
-        row[c] = (c <= i) ? A4[m] : V4[m];
-        wtile[2 * tslot(rho_inv(c), i >> 1) + (i & 1)] = V4[m];
+        for (int k = 0; k < 16; ++k) {
+            const bool mine = (lane < 16) ? (k <= lane) : (k > lane - 16);
+            if (mine) row[k] = v[k];
+        }
     }
+    publish_w(wtile, lane, v);
 }
 
 // Staging of a diagonal tile in trsm128: W_jj as an A operand from the factored tile G at Ljj -- W[n][k] =
