@@ -277,6 +277,28 @@ def main():
         dist.all_gather_into_tensor(allr, mine)
         per_rank = [{"rank": r, "fit_ms": float(v[0]), "alpha_ms": float(v[1]), "predict_ms": float(v[2])}
                     for r, v in enumerate(allr.view(world, 3).cpu().numpy())]
+        # one more step OUTSIDE the timed region with the schedule's self-diagnosis on (DistGP.profile): per rank and
+        # per kind, event-timed on the stream each piece runs on -- update launches, all-gathers, broadcasts, the main
+        # stream's wait for each panel (= what the panel chain costs the MFMA stream) -- and the host's issue time per
+        # step.  A sub-target scaling number can then be read: compute (update_ms against 1/world of the single-GPU
+        # update time), exposed communication (stall_panel_ms), or a host that cannot issue fast enough (host_issue_ms
+        # against the step's wall).
+        diag_all = None
+        if os.environ.get("GPMI_BENCH_NO_DIAG") != "1":
+            gp.profile(True)
+            barrier()
+            t1 = time.perf_counter()
+            step()
+            barrier()
+            diag = {"rank": rank, "step_wall_ms": (time.perf_counter() - t1) * 1e3}
+            for key, v in gp.profile_summary().items():
+                diag[key + "_ms"] = round(v["ms"], 3)
+                diag[key + "_n"] = v["n"]
+                if key in ("stall_panel", "host_issue", "allgather", "bcast"):
+                    diag[key + "_max_ms"] = round(v["max_ms"], 3)
+            gp.profile(False)
+            diag_all = [None] * world
+            dist.all_gather_object(diag_all, diag)
     ms_per_step = dt / args.steps * 1e3
     flops = algorithmic_flops(N, n)
     value = flops / (dt / args.steps) / 1e12
@@ -303,6 +325,14 @@ def main():
             out["config"]["block_rows"] = nb_used
             out["stages_ms"] = stage            # last step, rank 0: fit / alpha / predict wall
             out["per_rank_ms"] = per_rank
+            out["per_rank_diag"] = diag_all
+            out["per_rank_diag_note"] = ("one extra step outside the timed region, events on the stream each piece runs on: "
+                                         "update = trailing-update launches of the fit, allgather / bcast / pack = panel "
+                                         "collectives and the pack copy, stall_panel = main stream waiting for the panel "
+                                         "chain, diag / panel_solve = diagonal-block factorisations and panel solves, "
+                                         "*_v = predict sweep, alpha_* = backward solve, host_issue = host time to issue "
+                                         "each fit step")
+            out["comm"] = gp.comm.describe()
             if force_dist:
                 out["config"]["partition"] = "multi-rank driver forced on one rank (RCCL communicator of size 1)"
             targets["speedup_8gpu"] = {"target": TARGET_SPEEDUP_8, "note": "value at n_gpus=8 / value at n_gpus=1; "

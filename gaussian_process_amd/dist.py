@@ -49,6 +49,39 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class TorchComm:
+    """The collectives the schedule issues, on a torch.distributed process group ("nccl" = RCCL on ROCm; gloo in
+    the CPU tests).  DistGP only ever talks to an object with this interface (rank, size, broadcast, all_gather,
+    all_reduce), so a test can hand it an in-process stand-in and run G ranks as G threads of one process."""
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("DistGP needs torch.distributed (init_process_group) -- one rank per GPU")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+
+    def _src(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def broadcast(self, t, src):
+        dist.broadcast(t, src=self._src(src), group=self.group)
+
+    def all_gather(self, out, inp):
+        """out (size * len(inp)) <- every rank's inp, in rank order"""
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce(self, t, op="sum"):
+        dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM, group=self.group)
+
+    def describe(self):
+        """the backend and the RCCL / NCCL knobs in effect (bench line)"""
+        import os
+        knobs = {k: v for k, v in os.environ.items()
+                 if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HSA_FORCE_FINE_GRAIN", "TORCH_NCCL_"))}
+        return {"backend": dist.get_backend(self.group), "ranks": self.size, "env": knobs}
+
+
 class HipBlockOps:
     """Block primitives on torch CUDA tensors through libgpmi355x.so (gpmi_dev_*).
     Views must be float64 with unit column stride; ld = view.stride(0)."""
@@ -155,18 +188,39 @@ class HipBlockOps:
         torch.cuda.synchronize(self.device)
 
 
+class _Timed:
+    """events (CUDA) or host seconds (CPU stand-ins) around a piece of the schedule; see DistGP.profile"""
+
+    def __init__(self, gp, key, stream):
+        self.gp, self.key, self.stream = gp, key, stream
+
+    def _mark(self):
+        import time
+        if not self.gp._cuda():
+            return time.perf_counter()
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.gp.dev) if self.stream is None else self.gp._stream_of(self.stream))
+        return ev
+
+    def __enter__(self):
+        self.a = self._mark()
+
+    def __exit__(self, *exc):
+        if self.gp._prof is not None:
+            self.gp._prof.setdefault(self.key, []).append((self.a, self._mark()))
+
+
 class DistGP:
     """Row-block cyclic GP fit / predict over the ranks of `group` (default: WORLD)."""
 
     def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=2,
-                 force_collectives=False):
-        if not dist.is_initialized():
-            raise RuntimeError("DistGP needs torch.distributed (init_process_group) -- one rank per GPU")
+                 force_collectives=False, comm=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
+        self.comm = comm if comm is not None else TorchComm(group)
         self.group = group
-        self.rank = dist.get_rank(group)
-        self.G = dist.get_world_size(group)
+        self.rank = self.comm.rank
+        self.G = self.comm.size
         # a world of one rank needs no collective; force_collectives issues them anyway (every broadcast,
         # all-gather and all-reduce of the multi-rank schedule, on a communicator of size 1) so that the
         # RCCL call path can be exercised on a single GPU
@@ -184,10 +238,38 @@ class DistGP:
         self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
         self.have_test = False
         self.stage_ms = {}
+        self._prof = None            # profile(True): {key: [(start, end) events or (t0, t1) seconds]}
 
-    # ------------------------------------------------------------------ helpers
-    def _src(self, r):
-        return dist.get_global_rank(self.group, r) if self.group is not None else r
+    # ------------------------------------------------------------------ self-diagnosis (bench line)
+    def profile(self, on=True):
+        """Switch per-kind timing of the schedule on or off.  While on, every collective, every update launch, the
+        panel solves and the diagonal-block factorisations are bracketed by events on the stream they run on, the
+        main stream's wait for the panel of each step is bracketed too (that elapsed time IS the stall), and the host
+        clocks each step's issue.  A handful of event records per step: meant for one diagnostic step outside the
+        timed region (bench.py), not for the timed steps."""
+        self._prof = {} if on else None
+
+    def _timed(self, key, stream="main"):
+        """context manager: events around the enclosed work on the named stream (seconds on the host for CPU ops)"""
+        import contextlib
+        if self._prof is None:
+            return contextlib.nullcontext()
+        return _Timed(self, key, stream)
+
+    def profile_summary(self):
+        """{key: {"ms": summed elapsed, "n": count, "max_ms": largest}} after a synchronisation; keys: update (every
+        trailing-update launch of the fit), allgather, pack, bcast, panel_solve, diag, stall_panel (main stream
+        waiting for the panel chain), update_v / bcast_v / solve_v (predict sweep), alpha_gather / alpha_gemv /
+        alpha_solve, host_issue (host seconds per step of the fit loop, reported in ms)."""
+        if self._prof is None:
+            return {}
+        if self._cuda():
+            torch.cuda.synchronize(self.dev)
+        out = {}
+        for key, pairs in self._prof.items():
+            vals = [(a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3) for a, b in pairs]
+            out[key] = {"ms": float(sum(vals)), "n": len(vals), "max_ms": float(max(vals)) if vals else 0.0}
+        return out
 
     def _lstart(self, k, r=None):
         """first local block index of rank r whose global block index is > k"""
@@ -220,8 +302,8 @@ class DistGP:
         self.X = torch.from_numpy(X).to(self.dev)
         self.y = torch.from_numpy(y).to(self.dev)
         if self.coll:
-            dist.broadcast(self.X, src=self._src(0), group=self.group)
-            dist.broadcast(self.y, src=self._src(0), group=self.group)
+            self.comm.broadcast(self.X, 0)
+            self.comm.broadcast(self.y, 0)
         self.A = self._tensor(max(self.rows, 1), self.ld)
         self.Lkk = self._tensor(NB, NB)
         cmax = max(self._nblocks(r) for r in range(G))
@@ -296,6 +378,23 @@ class DistGP:
         self.rowmapC_h = np.ascontiguousarray(flatC or [0], dtype=np.int32)
         self.have_factor = False
         self.have_test = False
+
+    def _concurrent(self, on):
+        """context manager: the block primitives' beside-an-update forms (gpmi_dev_set_concurrent) for the enclosed sweep"""
+        import contextlib
+        ops = self.ops
+
+        @contextlib.contextmanager
+        def scope():
+            if hasattr(ops, "set_concurrent") and on:
+                ops.set_concurrent(True)
+                try:
+                    yield
+                finally:
+                    ops.set_concurrent(False)
+            else:
+                yield
+        return scope()
 
     # ------------------------------------------------------------------ streams (no-ops on CPU)
     def _cuda(self):
@@ -375,8 +474,10 @@ class DistGP:
         cmax = max(cnts)
         cnt = cnts[self.rank]
         if cnt:
-            self.send[:cnt * NB * NB].view(cnt * NB, NB).copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
-        dist.all_gather_into_tensor(buf[:G * cmax * NB * NB], self.send[:cmax * NB * NB], group=self.group)
+            with self._timed("pack", None):
+                self.send[:cnt * NB * NB].view(cnt * NB, NB).copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
+        with self._timed("allgather", None):
+            self.comm.all_gather(buf[:G * cmax * NB * NB], self.send[:cmax * NB * NB])
 
     def _pblock(self, k, buf, i):
         """block k + 1 + i of panel column k as an NB x NB tensor"""
@@ -390,18 +491,19 @@ class DistGP:
     def _update(self, k, buf, Cm, Am, first, rowmap=None, rowmap_h=None):
         """Cm -= Am * (panel column k from its block `first` on)^T, columns of Cm in natural block order"""
         ops, NB = self.ops, self.NB
-        if not self.coll:
-            r0 = (self._lstart(k) + first) * NB
-            nrow = Cm.shape[1]
-            P = self.A[r0:r0 + nrow, k * NB:(k + 1) * NB]
-            if rowmap is None:
-                ops.gemm_nt(Cm, Am, P)
-            else:
-                ops.gemm_nt_rowmap(Cm, Am, P, rowmap, 128, rowmap_h)
-            return
-        s0 = self.boff_start[k] + first
-        nblk = Cm.shape[1] // NB
-        ops.gemm_nt_blocks(Cm, Am, buf, NB, self.boff[s0:s0 + nblk], NB, rowmap, 128, rowmap_h)
+        with self._timed("update", None):
+            if not self.coll:
+                r0 = (self._lstart(k) + first) * NB
+                nrow = Cm.shape[1]
+                P = self.A[r0:r0 + nrow, k * NB:(k + 1) * NB]
+                if rowmap is None:
+                    ops.gemm_nt(Cm, Am, P)
+                else:
+                    ops.gemm_nt_rowmap(Cm, Am, P, rowmap, 128, rowmap_h)
+                return
+            s0 = self.boff_start[k] + first
+            nblk = Cm.shape[1] // NB
+            ops.gemm_nt_blocks(Cm, Am, buf, NB, self.boff[s0:s0 + nblk], NB, rowmap, 128, rowmap_h)
 
     def _panel_step(self, k, buf):
         """Block column k: owner factors the diagonal block, broadcast, every rank solves its
@@ -412,15 +514,18 @@ class DistGP:
         if self.rank == owner:
             li = k // G
             diag = A[li * NB:(li + 1) * NB, c0:c0 + NB]
-            ops.potrf_block(diag, c0, self.info)
-            self.Lkk.copy_(diag)
+            with self._timed("diag", None):
+                ops.potrf_block(diag, c0, self.info)
+                self.Lkk.copy_(diag)
         if self.coll:
-            dist.broadcast(self.Lkk, src=self._src(owner), group=self.group)
+            with self._timed("bcast", None):
+                self.comm.broadcast(self.Lkk, owner)
         ls = self._lstart(k)
         r0 = ls * NB
         m = self.rows - r0
         if m > 0:
-            ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
+            with self._timed("panel_solve", None):
+                ops.trsm_block(self.Lkk, A[r0:r0 + m, c0:c0 + NB])
         if k == self.T - 1 or not self.coll:
             return
         self._gather_panel(k, buf, r0)
@@ -443,13 +548,17 @@ class DistGP:
         with self._on("crit"):
             if self.rank == 0 % G:
                 diag = A[0:NB, 0:NB]
-                ops.potrf_block(diag, 0, self.info)
-                Lk[0].copy_(diag)
+                with self._timed("diag", None):
+                    ops.potrf_block(diag, 0, self.info)
+                    Lk[0].copy_(diag)
             if self.coll:
-                dist.broadcast(Lk[0], src=self._src(0), group=self.group)
+                with self._timed("bcast", None):
+                    self.comm.broadcast(Lk[0], 0)
         ev_bcast = self._record("crit")
         ev_panel_prev = None                             # side-stream work of step k-1 (last reader of Lk[(k+1) % 2])
+        import time
         for k in range(T):
+            t_issue = time.perf_counter()
             Lcur = Lk[k % 2]
             buf = self.Pbuf[k % 2]
             c0, c1 = k * NB, (k + 1) * NB
@@ -463,19 +572,22 @@ class DistGP:
                 self._wait("crit", ev_a)                 # its columns <= k+1 are final up to step k-1
                 with self._on("crit"):
                     blk = A[ls * NB:(ls + 1) * NB, c0:c0 + NB]
-                    ops.trsm_block(Lcur, blk)
+                    with self._timed("diag", None):
+                        ops.trsm_block(Lcur, blk)
                     ev_row = self._record("crit")
                     dk = A[ls * NB:(ls + 1) * NB, c1:c1 + NB]
-                    ops.gemm_nt(dk, blk, blk)
-                    ops.potrf_block(dk, c1, self.info)
-                    Lk[(k + 1) % 2].copy_(dk)
+                    with self._timed("diag", None):
+                        ops.gemm_nt(dk, blk, blk)
+                        ops.potrf_block(dk, c1, self.info)
+                        Lk[(k + 1) % 2].copy_(dk)
             self._wait("side", ev_bcast)                 # L_kk has arrived
             self._wait("side", ev_a)                     # block column k carries every update before step k
             with self._on("side"):
                 r_rest = (ls + 1) * NB if own_next else ls * NB
                 m = self.rows - r_rest
                 if m > 0:
-                    ops.trsm_block(Lcur, A[r_rest:r_rest + m, c0:c0 + NB])
+                    with self._timed("panel_solve", None):
+                        ops.trsm_block(Lcur, A[r_rest:r_rest + m, c0:c0 + NB])
                 if k < T - 1 and self.coll:
                     self._wait("side", ev_row)
                     self._gather_panel(k, buf, ls * NB)
@@ -486,25 +598,31 @@ class DistGP:
                 break
             with self._on("crit"):                       # queued behind the owner's potrf on this stream
                 if self.coll:
-                    dist.broadcast(Lk[(k + 1) % 2], src=self._src((k + 1) % G), group=self.group)
+                    with self._timed("bcast", None):
+                        self.comm.broadcast(Lk[(k + 1) % 2], (k + 1) % G)
             ev_bcast = self._record("crit")
-            self._wait("main", ev_panel)
+            with self._timed("stall_panel", "main"):      # elapsed between these two events = main-stream time lost to the panel chain
+                self._wait("main", ev_panel)
             if not self.coll:
                 self._wait("main", ev_row)
             r1 = self._lstart(k + 1) * NB                # my rows of blocks > k+1 (and the y rows)
             m1 = self.rows - r1
             if m1 > 0:                                   # (a) block column k+1 below its diagonal block
-                ops.gemm_nt(A[r1:r1 + m1, c1:c1 + NB], A[r1:r1 + m1, c0:c0 + NB], self._pblock(k, buf, 0))
+                with self._timed("update", None):
+                    ops.gemm_nt(A[r1:r1 + m1, c1:c1 + NB], A[r1:r1 + m1, c0:c0 + NB], self._pblock(k, buf, 0))
             ls1 = self._lstart(k + 1)
             if k + 2 < T and ls1 < self.nloc and self.my_blocks[ls1] == k + 2:
                 # (a2) the diagonal block of my block row k+2: everything the next critical step reads
                 rows = slice(ls1 * NB, (ls1 + 1) * NB)
-                ops.gemm_nt(A[rows, c1 + NB:c1 + 2 * NB], A[rows, c0:c0 + NB], self._pblock(k, buf, 1))
+                with self._timed("update", None):
+                    ops.gemm_nt(A[rows, c1 + NB:c1 + 2 * NB], A[rows, c0:c0 + NB], self._pblock(k, buf, 1))
             ev_a = self._record("main")
             if k + 2 < T and m1 > 0:                     # (b) the remaining columns
                 off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
                 self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
                              self.rowmapC[off:off + ln], self.rowmapC_h[off:off + ln])
+            if self._prof is not None:
+                self._prof.setdefault("host_issue", []).append((t_issue, time.perf_counter()))
         self._wait("main", ev_bcast)
         self._wait("main", self._record("crit"))
 
@@ -534,49 +652,50 @@ class DistGP:
             A[self.yrow:self.yrow + YB, :self.Np].zero_()
             A[self.yrow, :self.N].copy_(self.y)
         T = self.T
-        if hasattr(ops, "set_concurrent"):
-            ops.set_concurrent(bool(self.lookahead))      # panel primitives run beside the update on other streams
-        if self.lookahead >= 2:
-            self._factor_critical_path_first()
-        elif not self.lookahead:
-            for k in range(T):
-                self._panel_step(k, self.Pbuf[0])
-                if k == T - 1:
-                    break
-                r0 = self._lstart(k) * NB
-                m = self.rows - r0
-                if m > 0:
-                    off, ln = self.rowmap_off[k], self.rowmap_len[k]
-                    self._update(k, self.Pbuf[0], A[r0:r0 + m, (k + 1) * NB:self.Np], A[r0:r0 + m, k * NB:(k + 1) * NB], 0,
-                                 self.rowmap[off:off + ln], self.rowmap_h[off:off + ln])
-        else:
-            self._order(first_is_side=False)              # side waits for the K build
-            with self._side():
-                self._panel_step(0, self.Pbuf[0])
-            for k in range(T - 1):
-                self._order(first_is_side=True)           # main waits for panel k
-                buf = self.Pbuf[k % 2]
-                c0, c1 = k * NB, (k + 1) * NB
-                r0 = self._lstart(k) * NB                 # my rows of blocks > k (and the y rows)
-                m = self.rows - r0
-                if m > 0:                                 # (a) block column k+1
-                    ops.gemm_nt(A[r0:r0 + m, c1:c1 + NB], A[r0:r0 + m, c0:c0 + NB], self._pblock(k, buf, 0))
-                self._order(first_is_side=False)          # side waits for (a)
+        # panel primitives run beside the update on other streams: their small-LDS forms while the sweep is in flight;
+        # switched back on every way out (an exception in a collective must not leave the thread-local flag on)
+        with self._concurrent(bool(self.lookahead)):
+            if self.lookahead >= 2:
+                self._factor_critical_path_first()
+            elif not self.lookahead:
+                for k in range(T):
+                    self._panel_step(k, self.Pbuf[0])
+                    if k == T - 1:
+                        break
+                    r0 = self._lstart(k) * NB
+                    m = self.rows - r0
+                    if m > 0:
+                        off, ln = self.rowmap_off[k], self.rowmap_len[k]
+                        self._update(k, self.Pbuf[0], A[r0:r0 + m, (k + 1) * NB:self.Np], A[r0:r0 + m, k * NB:(k + 1) * NB], 0,
+                                     self.rowmap[off:off + ln], self.rowmap_h[off:off + ln])
+            else:
+                self._order(first_is_side=False)              # side waits for the K build
                 with self._side():
-                    self._panel_step(k + 1, self.Pbuf[(k + 1) % 2])
-                if k + 2 < T:                             # (b) the remaining columns
-                    r1 = self._lstart(k + 1) * NB         # my rows of blocks > k+1 (and the y rows)
-                    m1 = self.rows - r1
-                    if m1 > 0:
-                        off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
-                        self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
-                                     self.rowmapB[off:off + ln], self.rowmapB_h[off:off + ln])
-            self._order(first_is_side=True)               # main waits for the last panel
-        if hasattr(ops, "set_concurrent"):
-            ops.set_concurrent(False)
+                    self._panel_step(0, self.Pbuf[0])
+                for k in range(T - 1):
+                    with self._timed("stall_panel", "main"):
+                        self._order(first_is_side=True)       # main waits for panel k
+                    buf = self.Pbuf[k % 2]
+                    c0, c1 = k * NB, (k + 1) * NB
+                    r0 = self._lstart(k) * NB                 # my rows of blocks > k (and the y rows)
+                    m = self.rows - r0
+                    if m > 0:                                 # (a) block column k+1
+                        with self._timed("update", None):
+                            ops.gemm_nt(A[r0:r0 + m, c1:c1 + NB], A[r0:r0 + m, c0:c0 + NB], self._pblock(k, buf, 0))
+                    self._order(first_is_side=False)          # side waits for (a)
+                    with self._side():
+                        self._panel_step(k + 1, self.Pbuf[(k + 1) % 2])
+                    if k + 2 < T:                             # (b) the remaining columns
+                        r1 = self._lstart(k + 1) * NB         # my rows of blocks > k+1 (and the y rows)
+                        m1 = self.rows - r1
+                        if m1 > 0:
+                            off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
+                            self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
+                                         self.rowmapB[off:off + ln], self.rowmapB_h[off:off + ln])
+                self._order(first_is_side=True)               # main waits for the last panel
         # not-PD: smallest failing global column over all ranks
         if self.coll:
-            dist.all_reduce(self.info, op=dist.ReduceOp.MIN, group=self.group)
+            self.comm.all_reduce(self.info, "min")
         info = int(self.info.item())
         if info != INT64_MAX and info < self.N:
             err = np.linalg.LinAlgError("Matrix is not positive definite")
@@ -592,8 +711,8 @@ class DistGP:
         part = torch.stack([self.red[:max(self.nloc, 1), 0].sum(), self.red[self.nloc, 1]])
         if self.coll:
             allp = self._tensor(G * 2)
-            dist.all_gather_into_tensor(allp, part.contiguous(), group=self.group)
-            dist.broadcast(self.m, src=self._src(self.ry), group=self.group)
+            self.comm.all_gather(allp, part.contiguous())
+            self.comm.broadcast(self.m, self.ry)
         else:
             allp = part
         allp = allp.view(G, 2).cpu().numpy()
@@ -614,7 +733,7 @@ class DistGP:
         self.n_p = _round_up(self.n, 128)
         self.Xs = torch.from_numpy(Xs).to(self.dev)
         if self.coll:
-            dist.broadcast(self.Xs, src=self._src(0), group=self.group)
+            self.comm.broadcast(self.Xs, 0)
         self.ldv = max(self.nloc, 1) * self.NB + self.ld_pad
         self.V = self._tensor(self.n_p, self.ldv)
         self.Xk = [self._tensor(self.n_p, self.NB) for _ in range(2)]
@@ -632,65 +751,68 @@ class DistGP:
         import time
         t_begin = time.perf_counter()
         ops, NB, G, A, V = self.ops, self.NB, self.G, self.A, self.V
-        if hasattr(ops, "set_concurrent"):
-            ops.set_concurrent(bool(self.lookahead))
-        for li, b in enumerate(self.my_blocks):
-            ops.rbf_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, self.d, self.n_p, NB,
-                          self.sigma, self.ell, V[:, li * NB:(li + 1) * NB])
-            self.m_loc[li * NB:(li + 1) * NB].copy_(self.m[b * NB:(b + 1) * NB])
-        T = self.T
+        with self._concurrent(bool(self.lookahead)):
+            for li, b in enumerate(self.my_blocks):
+                ops.rbf_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, self.d, self.n_p, NB,
+                              self.sigma, self.ell, V[:, li * NB:(li + 1) * NB])
+                self.m_loc[li * NB:(li + 1) * NB].copy_(self.m[b * NB:(b + 1) * NB])
+            T = self.T
 
-        def solve_block(k, Xk):
-            """owner: v^T block k <- block * L_kk^-T; everyone receives it in Xk"""
-            if self.rank == k % G:
-                li = k // G
-                blk = V[:, li * NB:(li + 1) * NB]
-                ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
-                if self.coll:
-                    Xk.copy_(blk)
-            if self.coll and k < T - 1:
-                dist.broadcast(Xk, src=self._src(k % G), group=self.group)
+            def solve_block(k, Xk):
+                """owner: v^T block k <- block * L_kk^-T; everyone receives it in Xk"""
+                if self.rank == k % G:
+                    li = k // G
+                    blk = V[:, li * NB:(li + 1) * NB]
+                    with self._timed("solve_v", None):
+                        ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
+                        if self.coll:
+                            Xk.copy_(blk)
+                if self.coll and k < T - 1:
+                    with self._timed("bcast_v", None):
+                        self.comm.broadcast(Xk, k % G)
 
-        def xk_view(k):
-            return self.Xk[k % 2] if self.coll else V[:, k * NB:(k + 1) * NB]
+            def xk_view(k):
+                return self.Xk[k % 2] if self.coll else V[:, k * NB:(k + 1) * NB]
 
-        if not self.lookahead:
-            for k in range(T):
-                solve_block(k, self.Xk[0])
-                if k == T - 1:
-                    break
-                ls = self._lstart(k)
-                if self.nloc - ls > 0:
-                    ops.gemm_nt(V[:, ls * NB:self.nloc * NB], self.Xk[0] if self.coll else xk_view(k),
-                                A[ls * NB:self.nloc * NB, k * NB:(k + 1) * NB])
-        else:
-            self._order(first_is_side=False)
-            with self._side():
-                solve_block(0, self.Xk[0])
-            for k in range(T - 1):
-                self._order(first_is_side=True)            # main waits for solved block k
-                Xk = xk_view(k)
-                c0 = k * NB
-                ls = self._lstart(k)
-                own_next = (self.rank == (k + 1) % G)
-                if own_next:                               # (a) my block k+1 first
-                    li = (k + 1) // G
-                    ops.gemm_nt(V[:, li * NB:(li + 1) * NB], Xk, A[li * NB:(li + 1) * NB, c0:c0 + NB])
+            if not self.lookahead:
+                for k in range(T):
+                    solve_block(k, self.Xk[0])
+                    if k == T - 1:
+                        break
+                    ls = self._lstart(k)
+                    if self.nloc - ls > 0:
+                        with self._timed("update_v", None):
+                            ops.gemm_nt(V[:, ls * NB:self.nloc * NB], self.Xk[0] if self.coll else xk_view(k),
+                                        A[ls * NB:self.nloc * NB, k * NB:(k + 1) * NB])
+            else:
                 self._order(first_is_side=False)
                 with self._side():
-                    solve_block(k + 1, self.Xk[(k + 1) % 2])
-                lb = self._lstart(k + 1)                   # (b) my blocks beyond k+1
-                if self.nloc - lb > 0:
-                    ops.gemm_nt(V[:, lb * NB:self.nloc * NB], Xk, A[lb * NB:self.nloc * NB, c0:c0 + NB])
-            self._order(first_is_side=True)
-        if hasattr(ops, "set_concurrent"):
-            ops.set_concurrent(False)
+                    solve_block(0, self.Xk[0])
+                for k in range(T - 1):
+                    with self._timed("stall_v", "main"):
+                        self._order(first_is_side=True)        # main waits for solved block k
+                    Xk = xk_view(k)
+                    c0 = k * NB
+                    ls = self._lstart(k)
+                    own_next = (self.rank == (k + 1) % G)
+                    if own_next:                               # (a) my block k+1 first
+                        li = (k + 1) // G
+                        with self._timed("update_v", None):
+                            ops.gemm_nt(V[:, li * NB:(li + 1) * NB], Xk, A[li * NB:(li + 1) * NB, c0:c0 + NB])
+                    self._order(first_is_side=False)
+                    with self._side():
+                        solve_block(k + 1, self.Xk[(k + 1) % 2])
+                    lb = self._lstart(k + 1)                   # (b) my blocks beyond k+1
+                    if self.nloc - lb > 0:
+                        with self._timed("update_v", None):
+                            ops.gemm_nt(V[:, lb * NB:self.nloc * NB], Xk, A[lb * NB:self.nloc * NB, c0:c0 + NB])
+                self._order(first_is_side=True)
         self.dots.zero_()
         if self.nloc:
             ops.row_dots(V, self.nloc * NB, self.m_loc, self.dots[0], self.dots[1])
         if self.coll:
             alld = self._tensor(G * 2 * self.n_p)
-            dist.all_gather_into_tensor(alld, self.dots.view(-1), group=self.group)
+            self.comm.all_gather(alld, self.dots.view(-1))
         else:
             alld = self.dots
         alld = alld.view(G, 2, self.n_p).cpu().numpy()
@@ -725,7 +847,7 @@ class DistGP:
         if self.nloc:
             ops.gemm_nt(Gm[:, :n_p], self.V[:, :self.nloc * NB], self.V[:, :self.nloc * NB])     # Gm = -v_loc^T v_loc
         if self.coll:
-            dist.all_reduce(Gm, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm.all_reduce(Gm, "sum")
         ops.rbf_rows(self.Xs, self.n, self.d, 0, n_p, n_p, self.sigma, self.ell, float(jitter), P)
         P[:, :n_p].add_(Gm[:, :n_p])
         info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
@@ -771,7 +893,7 @@ class DistGP:
             if k == T - 1:
                 break
             if self.coll:
-                dist.broadcast(Xk[:m], src=self._src(k % G), group=self.group)
+                self.comm.broadcast(Xk[:m], k % G)
             src = Xk[:m] if self.coll else U[:m, (k // G) * NB:(k // G + 1) * NB]
             ls = self._lstart(k)
             if self.nloc - ls > 0:
@@ -793,7 +915,7 @@ class DistGP:
                                partial, out2)
         if self.coll:
             allp = self._tensor(G * 2)
-            dist.all_gather_into_tensor(allp, out2, group=self.group)
+            self.comm.all_gather(allp, out2)
         else:
             allp = out2
         allp = allp.view(G, 2).cpu().numpy()
@@ -826,12 +948,14 @@ class DistGP:
             c0 = k * NB
             ls = self._lstart(k)
             r0, r1 = ls * NB, self.nloc * NB
-            if r1 > r0:
-                ops.gemv_t(A[r0:r1, c0:c0 + NB], aloc[r0:r1], part, scratch)
-            else:
-                part.zero_()
+            with self._timed("alpha_gemv", None):
+                if r1 > r0:
+                    ops.gemv_t(A[r0:r1, c0:c0 + NB], aloc[r0:r1], part, scratch)
+                else:
+                    part.zero_()
             if self.coll:
-                dist.all_gather_into_tensor(allp, part, group=self.group)
+                with self._timed("alpha_gather", None):
+                    self.comm.all_gather(allp, part)
             else:
                 allp.copy_(part)
             if self.rank == k % G:
@@ -839,10 +963,11 @@ class DistGP:
                 rhs.copy_(self.m[c0:c0 + NB])
                 # one reduction kernel over the G contributions (a fixed tree for a given G and nb: the same
                 # bits on every run), not G tiny launches on the latency chain of the block
-                rhs.sub_(allp.view(G, NB).sum(dim=0))
-                ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs, inverted=li in self._vinv_blocks)
-                self._vinv_blocks.add(li)
-                aloc[li * NB:(li + 1) * NB].copy_(rhs)
+                with self._timed("alpha_solve", None):
+                    rhs.sub_(allp.view(G, NB).sum(dim=0))
+                    ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs, inverted=li in self._vinv_blocks)
+                    self._vinv_blocks.add(li)
+                    aloc[li * NB:(li + 1) * NB].copy_(rhs)
         # assemble the full vector in natural block order
         cmax = max(self._nblocks(r) for r in range(G))
         send = self._tensor(cmax * NB)
@@ -850,7 +975,7 @@ class DistGP:
         send[:self.nloc * NB].copy_(aloc[:self.nloc * NB])
         if self.coll:
             recv = self._tensor(G * cmax * NB)
-            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.comm.all_gather(recv, send)
         else:
             recv = send
         R = recv.view(G, cmax, NB).cpu().numpy()

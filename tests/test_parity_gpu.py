@@ -20,6 +20,7 @@ LML_RTOL = 1e-10
 ALPHA_RTOL = 1e-8     # relative to max|alpha| (alpha carries cond(K+sI) * eps)
 M_RTOL = 1e-9
 DIAG_RTOL = 1e-11
+RESID_ATOL = 1e-7     # sampled rows of (K + sI) alpha - y, scaled by max(1, max|alpha| / 1000) (set from what the sizes show)
 FPOST_ATOL = 1e-6     # Cholesky of the jitter-regularised posterior covariance
 
 
@@ -420,7 +421,8 @@ def _check_solution_properties(ctx, X, y, Xs, sigma, ell, s, rows=24):
         ki = sigma ** 2 * np.exp(coef * ((X - X[i]) ** 2).sum(1))
         ki[i] += s
         worst = max(worst, abs(ki @ alpha - y[i]))
-    assert worst <= 1e-7 * max(1.0, np.abs(alpha).max() * 1e-3), worst
+    print("solution properties N=%d: worst |(K+sI)alpha - y| on %d rows = %.3g, max|alpha| = %.4g" % (len(X), rows, worst, np.abs(alpha).max()))
+    assert worst <= RESID_ATOL * max(1.0, np.abs(alpha).max() * 1e-3), worst
     # y^T alpha == m^T m (the identity the LML uses)
     assert abs(y @ alpha - m @ m) <= 1e-8 * abs(m @ m)
     mu, var = ctx.predict(Xs, want_sd=False)
@@ -436,11 +438,36 @@ def _check_solution_properties(ctx, X, y, Xs, sigma, ell, s, rows=24):
     return lml
 
 
-def test_cfg3_N65536_d8_properties(ctx, oracle):
-    """BASELINE config 3 (the headline size): no CPU oracle can run it,
-    so it is checked through size-independent properties."""
-    X, y, Xs = oracle.synthetic_problem(65536, 8, 4096)
-    _check_solution_properties(ctx, X, y, Xs, 1.0, 2.0, 5e-4)
+def test_cfg3_N65536_d8_vs_fullsize_oracle(ctx, oracle):
+    """BASELINE config 3, the headline size, against the CPU oracle AT THAT SIZE.
+
+    tests/golden/oracle_N65536_d8.npz holds the outputs of oracle.fit_predict_feasible (this repo's pinned restatement
+    of GP_regression.py:138-148 and tune_hyperparms_regression.py:312 -- ORACLE-generated, not reference-generated:
+    the reference's own kernel build needs 275 GB here) from one run on a GPU box's 256 host cores (199 s; the command
+    is in scripts/oracle_fullsize.py, the log in profiles/r03_oracle_fullsize.log): mu and var at all 4096 test
+    points, the LML, and every 8th entry of alpha, m and diag(L).  Measured when the fixture was made
+    (profiles/r03_oracle_fullsize_diff.json): |dmu| 1.0e-10, |dvar| 2.6e-14, LML 5.7e-13 relative, alpha 5.6e-11 of
+    max|alpha| = 3125, diag L 6.7e-12 relative.  Asserted: north_star's 1e-8 on the mean with a decade to spare, the
+    rest at the tolerances of the small cases.  The size-independent properties are checked in the same pass."""
+    g = golden("oracle_N65536_d8")
+    N, d, n, st = int(g["N"]), int(g["d"]), int(g["n"]), int(g["stride"])
+    X, y, Xs = oracle.synthetic_problem(N, d, n, seed=int(g["seed"]))
+    lml = _check_solution_properties(ctx, X, y, Xs, float(g["sigma"]), float(g["ell"]), float(g["noise_var"]))
+    mu, var = ctx.predict(Xs, want_sd=False)
+    alpha, m, dg = ctx.alpha(), ctx.m(), ctx.diag()
+    amax = float(g["alpha_absmax"])
+    got = dict(dmu=np.max(np.abs(mu - g["mu"])), dvar=np.max(np.abs(var - g["var"])),
+               lml_rel=abs(lml - float(g["lml"])) / abs(float(g["lml"])),
+               alpha_rel=np.max(np.abs(alpha[::st] - g["alpha_s"])) / amax,
+               m_rel=np.max(np.abs(m[::st] - g["m_s"])) / np.max(np.abs(g["m_s"])),
+               diag_rel=np.max(np.abs(dg[::st] - g["diagL_s"]) / g["diagL_s"]))
+    print("cfg3 vs full-size oracle:", {k: float("%.3g" % v) for k, v in got.items()})
+    assert got["dmu"] <= MU_ATOL                  # 1e-9 (north_star: 1e-8)
+    assert got["dvar"] <= VAR_ATOL                # 1e-10
+    assert got["lml_rel"] <= LML_RTOL             # 1e-10
+    assert got["alpha_rel"] <= 1e-9               # the small cases allow 1e-8
+    assert got["m_rel"] <= 1e-9
+    assert got["diag_rel"] <= 1e-10
     t = ctx.timers()
     assert t["solve_v"] > 0 and t["ks"] > 0
 
