@@ -76,6 +76,7 @@ SIGNATURES = {
     "gpmi_dev_trsv_lt": [_vp, _vp, _i64, _vp, _i64],
     "gpmi_dev_trsv_lt_fused": [_vp, _vp, _i64, _vp, _vp, _i64],
     "gpmi_dev_trsv_lt_vinv": [_vp, _vp, _i64, _vp, _vp, _i64, C.c_int],
+    "gpmi_dev_trsv_lt_chain": [_vp, _vp, _i64, _vp, _vp, _vp, _i64, C.c_int, _vp],
     "gpmi_dev_set_concurrent": [C.c_int],
     "gpmi_dev_grad_trace": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp],
     "gpmi_dev_row_dots": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],

@@ -169,6 +169,16 @@ int gpmi_dev_trsv_lt_vinv(void* stream, double* L_dev, int64_t ld, double* b_dev
     return GPMI_OK;
 }
 
+int gpmi_dev_trsv_lt_chain(void* stream, double* L_dev, int64_t ld, double* vside_dev, const double* m_dev, double* x_dev,
+                           int64_t n, int invert, int* err_dev) {
+    if (!L_dev || !vside_dev || !m_dev || !x_dev || !err_dev || m_dev == x_dev)
+        return fail_arg("gpmi_dev_trsv_lt_chain: null or aliased pointer");
+    if (n <= 0 || n % TILE || ld % 2) return fail_arg("gpmi_dev_trsv_lt_chain: n must be a positive multiple of 128, ld even");
+    if (invert) HIP_TRY(launch_vinv128((hipStream_t)stream, L_dev, ld, n, vside_dev));
+    HIP_TRY(launch_trsv_lt_chain((hipStream_t)stream, L_dev, ld, vside_dev, m_dev, x_dev, n, err_dev));
+    return GPMI_OK;
+}
+
 // Tell the block primitives called from this thread that they run beside a trailing update on another stream
 // (the multi-rank driver's lookahead): the panel kernels then use their small-LDS forms (two-launch trsm128, shallow
 // ring for small GEMMs), which fit on a CU next to an update workgroup and start at once.  Results are the

@@ -241,6 +241,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     hipStream_t s = c->stream;
     c->have_factor = false;
     c->have_vinv = false;
+    c->have_vside = false;
     c->have_v = false;
     c->timers_reset({GPMI_T_KBUILD, GPMI_T_CHOL, GPMI_T_CHOL_PANEL, GPMI_T_CHOL_TRAIL, GPMI_T_LML,
                      GPMI_T_TRAIL_LAUNCHES, GPMI_T_TRAIL_FLOPS});

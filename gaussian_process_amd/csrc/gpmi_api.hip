@@ -71,7 +71,7 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->X, &c->y, &c->A, &c->info, &c->red, &c->Xs, &c->V, &c->P, &c->vec, &c->dense,
-                       &c->U, &c->Kn, &c->gpart, &c->cov_a, &c->cov_b, &c->cov_out})
+                       &c->U, &c->Kn, &c->gpart, &c->cov_a, &c->cov_b, &c->cov_out, &c->flag, &c->vside})
         b->release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
@@ -107,7 +107,8 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
     } else if (!strcmp(name, "gemm_persist")) {
         c->tune.gemm_persist = value ? 1 : 0;
     } else if (!strcmp(name, "trsv_vinv")) {
-        c->tune.trsv_vinv = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail_arg("trsv_vinv must be 0 (16 x 16 rounds), 1 (one launch per block) or 2 (one launch)");
+        c->tune.trsv_vinv = (int)value;
     } else if (!strcmp(name, "panel_fused")) {
         c->tune.panel_fused = value ? 1 : 0;
     } else if (!strcmp(name, "rbf_blocks")) {
@@ -310,11 +311,20 @@ int gpmi_get_factor_block(gpmi_ctx* c, int64_t r0, int64_t r1, int64_t c0, int64
 // blocks into their upper triangles (one launch, all blocks at once), every call then runs one product per block
 static hipError_t backward_solve_fused(gpmi_ctx* c, double* b, double* xout) {
     double* A = c->A.as<double>();
-    if (!tuning().trsv_vinv) return launch_trsv_lt_fused(c->stream, A, c->ldA, b, xout, c->Np);
-    if (!c->have_vinv) {
-        const hipError_t e = launch_vinv128(c->stream, A, c->ldA, c->Np);
+    const int mode = tuning().trsv_vinv;
+    if (!mode) return launch_trsv_lt_fused(c->stream, A, c->ldA, b, xout, c->Np);
+    hipError_t e;
+    if (mode >= 2 && (e = c->vside.ensure((size_t)c->Np * 128 * 8)) != hipSuccess) return e;
+    if (!c->have_vinv || (mode >= 2 && !c->have_vside)) {
+        e = launch_vinv128(c->stream, A, c->ldA, c->Np, mode >= 2 ? c->vside.as<double>() : nullptr);
         if (e != hipSuccess) return e;
         c->have_vinv = true;
+        c->have_vside = mode >= 2;
+    }
+    if (mode >= 2) {
+        if ((e = c->flag.ensure(64)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(c->flag.p, 0, 64, c->stream)) != hipSuccess) return e;
+        return launch_trsv_lt_chain(c->stream, A, c->ldA, c->vside.as<double>(), b, xout, c->Np, c->flag.as<int>());
     }
     return launch_trsv_lt_vinv(c->stream, A, c->ldA, b, xout, c->Np);
 }
@@ -340,8 +350,12 @@ int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
     }
     c->span_end(sp);
     HIP_TRY(hipMemcpyAsync(alpha_out, x, (size_t)c->N * 8, hipMemcpyDeviceToHost, s));
+    int gave_up = 0;
+    if (c->factor_fused && tuning().trsv_vinv >= 2)
+        HIP_TRY(hipMemcpyAsync(&gave_up, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->timers_collect();
+    if (gave_up) return fail_runtime(hipErrorUnknown, "gpmi_get_alpha: the single-launch backward solve gave up waiting for a block");
     return GPMI_OK;
 }
 

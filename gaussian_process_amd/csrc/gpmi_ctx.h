@@ -121,6 +121,9 @@ struct gpmi_ctx {
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;
+    DevBuf flag;             // one int the single-launch backward solve sets if a poll gave up
+    DevBuf vside;            // Np x 128: the inverses of the 128 x 128 diagonal blocks, row-major (launch_vinv128's side buffer)
+    bool have_vside = false; // vside matches the resident factor
     DevBuf cov_a, cov_b, cov_out;   // gpmi_rbf / gpmi_cov staging, kept across calls (the BO loops call them hundreds of times)
     DevBuf U, Kn, gpart;     // f2: L^-T, -(K+sI)^-1, per-tile partial sums of the gradient trace
     double sigma = 1.0, ell = 1.0;   // hyper-parameters of the resident factorisation

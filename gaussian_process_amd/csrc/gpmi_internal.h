@@ -22,7 +22,7 @@ struct Tuning {
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always
     int rbf_blocks = 16384;     // persistent blocks of the register-path K build
-    int trsv_vinv = 1;          // backward solve: 1 one product with the inverted 128 x 128 diagonal block per step, 0 the 16 x 16 rounds
+    int trsv_vinv = 2;          // backward solve: 2 one launch, column blocks chained through the solution vector (inverted 128 x 128 diagonal blocks); 1 one launch per 128 unknowns with the same inverses; 0 the 16 x 16 rounds
     int panel_fused = 1;        // 1: fused multi-column panel kernels, 0: first-generation potf2 + substitution leaves
     int gemm_small_dma = 1;     // 1: deep-prefetch LDS-DMA kernel for launches with few tiles, 0: first-generation 64 x 64 kernel
     int gemm_dbg = 0;           // timing-only ablation bits (gpmi_probe_gemm); results are wrong when non-zero
@@ -182,8 +182,13 @@ hipError_t launch_trsv_lt(hipStream_t s, const double* L, int64_t ld, double* b,
 // launch; n multiple of 128; b is destroyed, the solution goes to xout (must not alias b)
 hipError_t launch_trsv_lt_fused(hipStream_t s, const double* L, int64_t ld, double* b, double* xout, int64_t n);
 // full inverses of the 128 x 128 diagonal blocks into their upper triangles, and the backward solve that uses them
-hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n);
+// vside (optional, n * 128 doubles): V = L_kk^-1 itself, row-major 128 x 128 per block, for launch_trsv_lt_chain
+hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n, double* vside = nullptr);
 hipError_t launch_trsv_lt_vinv(hipStream_t s, const double* L, int64_t ld, double* b, double* xout, int64_t n);
+// the same in ONE launch (column blocks chained through the solution vector itself); m is only read; err_dev: one int,
+// set if a poll gave up
+hipError_t launch_trsv_lt_chain(hipStream_t s, const double* L, int64_t ld, const double* vside, const double* m,
+                                double* xout, int64_t n, int* err_dev);
 // y[c] = sum_r A[r][c] * x[r]; scratch: ceil(nrows/64) * ncols doubles
 hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nrows, int64_t ncols,
                          const double* x, double* y, double* scratch);

@@ -504,7 +504,11 @@ __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_
 // 16 x 16 solve-and-update rounds.  Only ever used for vectors (alpha); the factorisation itself and the
 // predictive solves keep to 16 x 16 inverses.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void vinv128_kernel(double* A, int64_t ld) {
+// vside (may be null): additionally V itself, row-major 128 x 128 per block with zeros above the diagonal and
+// diag(V) = 1 / diag(L) in place, block b at vside + b * 128 * 128 -- the single-launch backward solve (solve.hip)
+// streams it like one more block of L.  The caller zero-fills vside first (column tiles left of a wave's own are
+// never written).
+__global__ __launch_bounds__(256, 2) void vinv128_kernel(double* A, int64_t ld, double* vside) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     d2* tiles = reinterpret_cast<d2*>(smem);
     const int lane = threadIdx.x & 63;
@@ -539,6 +543,16 @@ __global__ __launch_bounds__(256, 2) void vinv128_kernel(double* A, int64_t ld) 
 #pragma unroll
         for (int k = 1; k < NT; ++k)
             if (k > i) store_xtile(Lb + (int64_t)(16 * i) * ld + 16 * k, ld, lane, xt[k]);
+        if (vside) {
+            // xt[k][v] = V^T[16 i + fr][16 k + kap(fg, v)] = V[16 k + kap(fg, v)][16 i + fr]: 16 lanes (fr) write 128 contiguous bytes
+            double* Vb = vside + (int64_t)blockIdx.x * PB * PB + 16 * i + (lane & 15);
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                if (k >= i) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Vb[(16 * k + kap(lane >> 4, v)) * PB] = xt[k][v];
+                }
+        }
     }
 }
 
@@ -582,11 +596,15 @@ hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X
     return hipGetLastError();
 }
 
-hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n) {
+hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n, double* vside) {
     if (n <= 0 || n % PB || ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15)) return hipErrorInvalidValue;
     hipError_t e = panel_mfma_attrs();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(vinv128_kernel, dim3((unsigned)(n / PB)), dim3(256), NTILES * TILE_BYTES, s, A, ld);
+    if (vside) {
+        e = hipMemsetAsync(vside, 0, (size_t)n * PB * sizeof(double), s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(vinv128_kernel, dim3((unsigned)(n / PB)), dim3(256), NTILES * TILE_BYTES, s, A, ld, vside);
     return hipGetLastError();
 }
 

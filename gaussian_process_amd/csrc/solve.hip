@@ -374,6 +374,170 @@ hipError_t launch_trsv_lt_vinv(hipStream_t s, const double* L, int64_t ld, doubl
     return hipGetLastError();
 }
 
+// ---- backward substitution, fourth generation: ONE launch, column blocks chained by the data itself ----------
+// The launch chain above spends ~4 us of every ~10 us step between launches, and its update of ALL columns is on the
+// path from x_j to x_(j-1).  Here the triangle is walked the other way round (left-looking): workgroup b owns the 128
+// columns of block k = T - 1 - b and accumulates  s_k = sum_(j > k) L_jk^T x_j  in registers while it streams its own
+// column panel bottom-up, then x_k = V_kk^T (m_k - s_k) with the block's inverse V_kk = L_kk^-1 from launch_vinv128's
+// side buffer (row-major, zeros above the diagonal: the product is the same column accumulation as a block of L, no
+// masks, no second thread mapping), and publishes x_k.
+//   * No flags: the solution vector is its own signal.  x is filled with a NaN pattern no arithmetic produces
+//     (all ones); a wave that needs x_j polls ITS 32 entries with agent-scope atomic loads until none of them is the
+//     pattern, and broadcasts them to the wave through v_readlane (the multiplier of every FMA is a scalar register,
+//     no LDS traffic, no workgroup barrier per step).  The publisher stores the entries with agent-scope atomic
+//     stores (write-through past the XCD's L2).  One memory round trip between x_j being stored and being used.
+//   * The panel is streamed in chunks of 64 rows x 128 columns (64 KiB: 16 rows per wave, whole 1-KiB row segments,
+//     a lane holds the column pair 2 lane, 2 lane + 1 of each row: 64 registers), three register buffers in rotation,
+//     each chunk requested two steps before it is used.  One poll per block (two chunks), issued BEFORE that step's
+//     request: the memory counter retires in order, so a poll behind a request would wait for the request's data.
+//   * Nothing on the path x_(k+1) -> x_k touches memory except that poll: when x_(k+1) appears the registers already
+//     hold both chunks of the sub-diagonal block and the lower half of V_kk, and V_kk's upper-left 64 x 64 quarter
+//     (its other quarter of the upper half is zero) sits in LDS since the start of the kernel.
+//   * Workgroups are dispatched in index order and workgroup b only ever waits for workgroups < b, so the chain
+//     cannot deadlock when T exceeds the resident capacity (2 per CU); a bounded poll makes every wave leave the
+//     kernel even if the input is garbage (the entry then reads as NaN and *err is set).
+// Summation order is fixed (rows in order inside a wave's 16, chunks bottom-up, the four waves' partials in order),
+// so the result does not depend on timing.
+constexpr unsigned long long TRSV_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
+constexpr int TRSV_MAX_POLLS = 1 << 22;
+
+__device__ __forceinline__ double trsv_poll(const double* p, int* err) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int polls = 0;
+    while (v == TRSV_SENTINEL) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++polls > TRSV_MAX_POLLS) { *err = 1; v = 0x7FF8000000000000ull; break; }
+    }
+    return __longlong_as_double((long long)v);
+}
+
+__device__ __forceinline__ double bcast_lane(double v, int srclane) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), srclane);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), srclane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__global__ __launch_bounds__(256, 2) void trsv_lt_chain_kernel(const double* __restrict__ L, int64_t ld,
+                                                                const double* __restrict__ vside,
+                                                                const double* __restrict__ m, double* x, int T,
+                                                                int* err) {
+    __shared__ __attribute__((aligned(16))) double v0s[64 * 64];     // V_kk[0:64, 0:64]
+    __shared__ double red[4][128];
+    __shared__ __attribute__((aligned(16))) double rs[128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = T - 1 - (int)blockIdx.x;
+    const int64_t k0 = (int64_t)k * 128;
+    const int n = 2 * (T - 1 - k);           // 64-row chunks of L below my diagonal block, walked bottom-up
+    // chunk i < n: rows 64 (2 T - 1 - i) .. + 63 of L (block j = T - 1 - i / 2: its upper half for odd i);
+    // chunk n: rows 64 .. 127 of V_kk (row stride 128).  Wave w: rows 16 w .. 16 w + 15 of the chunk.  The row base is
+    // wave-uniform (a scalar base plus one 32-bit lane offset: no vector addresses).
+    d2 bufA[16], bufB[16], bufC[16];
+    double a0 = 0., a1 = 0.;
+    const unsigned voff = (unsigned)lane * 16u;
+#define TRSV_LOAD(buf, i)                                                                            \
+    if ((i) <= n) {                                                                                  \
+        const bool dg_ = (i) == n;                                                                   \
+        const char* p_ = dg_ ? reinterpret_cast<const char*>(vside + (k0 + 64 + 16 * w) * 128)       \
+                             : reinterpret_cast<const char*>(L + ((int64_t)(2 * T - 1 - (i)) * 64 + 16 * w) * ld + k0); \
+        const int64_t st_ = dg_ ? 128 * 8 : ld * 8;                                                  \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_)                                            \
+            buf[r_] = *reinterpret_cast<const d2*>(p_ + r_ * st_ + voff);                            \
+    }
+#define TRSV_FMA(buf, xv, lane0)                                                                     \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) {                                              \
+        const double xi_ = bcast_lane(xv, (lane0) + r_);                                             \
+        a0 = fma(buf[r_].x, xi_, a0);                                                                \
+        a1 = fma(buf[r_].y, xi_, a1);                                                                \
+    }
+    // one chunk.  Even i (the lower half of a block of L comes first): poll my 32 entries of that block's x -- lanes
+    // 0-15 the lower half's, lanes 16-31 the upper half's -- then request the chunk two ahead.  i == n: r_k = m_k - s_k
+    // (the four waves' partial sums in a fixed order) takes the place of x.
+#define TRSV_STEP(cur, nxt2, i)                                                                      \
+    {                                                                                                \
+        if ((i) == n) {                                                                              \
+            red[w][2 * lane] = a0;                                                                   \
+            red[w][2 * lane + 1] = a1;                                                               \
+            __syncthreads();                                                                         \
+            if (tid < 128) rs[tid] = mk - (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]); \
+            __syncthreads();                                                                         \
+            a0 = a1 = 0.;                                                                            \
+            xv = rs[64 + 16 * w + (lane & 15)];                                                      \
+        } else if (!((i) & 1)) {                                                                     \
+            const int64_t j0_ = (int64_t)(T - 1 - (i) / 2) * 128;                                    \
+            xv = trsv_poll(x + j0_ + ((lane & 16) ? 0 : 64) + 16 * w + (lane & 15), &lerr);          \
+        }                                                                                            \
+        TRSV_LOAD(nxt2, (i) + 2)                                                                     \
+        TRSV_FMA(cur, xv, 16 * ((i) & 1))                                                            \
+    }
+    int lerr = 0;
+    TRSV_LOAD(bufA, 0)
+    TRSV_LOAD(bufB, 1)
+    const double mk = (tid < 128) ? m[k0 + tid] : 0.0;
+    {   // V_kk[0:64, 0:64] -> LDS (thread: row tid / 4, 16 columns)
+        const double* src = vside + (k0 + (tid >> 2)) * 128 + 16 * (tid & 3);
+        d2 t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = *reinterpret_cast<const d2*>(src + 2 * q);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<d2*>(v0s + (tid >> 2) * 64 + 16 * (tid & 3) + 2 * q) = t[q];
+    }
+    double xv = 0.;
+    // three steps per trip so that the buffers are compile-time names (a runtime buffer index would put them in
+    // scratch memory)
+    for (int i = 0;; i += 3) {
+        TRSV_STEP(bufA, bufC, i)
+        if (i == n) break;
+        TRSV_STEP(bufB, bufA, i + 1)
+        if (i + 1 == n) break;
+        TRSV_STEP(bufC, bufB, i + 2)
+        if (i + 2 == n) break;
+    }
+    // the upper half of V_kk from LDS (columns 0 .. 63 only: lanes 0 .. 31); the barriers of step n ordered its writes
+    if (lane < 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const double xi = rs[16 * w + r];
+            const d2 v = *reinterpret_cast<const d2*>(v0s + (16 * w + r) * 64 + 2 * lane);
+            a0 = fma(v.x, xi, a0);
+            a1 = fma(v.y, xi, a1);
+        }
+    }
+    // x_k = V^T r_k: the four waves' partial sums in a fixed order, and the store that releases the next workgroup
+    __syncthreads();
+    red[w][2 * lane] = a0;
+    red[w][2 * lane + 1] = a1;
+    __syncthreads();
+    if (tid < 128) {
+        const double xk = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        unsigned long long bits = (unsigned long long)__double_as_longlong(xk);
+        if (bits == TRSV_SENTINEL) bits = 0x7FF8000000000000ull;      // a NaN stays a NaN, never the "not yet" pattern
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(x + k0 + tid), bits, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lerr) *err = 1;
+#undef TRSV_LOAD
+#undef TRSV_FMA
+#undef TRSV_STEP
+}
+
+// Solves L^T x = m in one launch for a fused factor; vside = the inverses of its 128 x 128 diagonal blocks as
+// launch_vinv128 writes them to its side buffer (n % 128 == 0).  m is only read; xout (n doubles, no alias) is first
+// filled with the "not yet" pattern.  err_dev: one int the kernel sets if a poll gave up (it never does on a finite
+// factor).
+hipError_t launch_trsv_lt_chain(hipStream_t s, const double* L, int64_t ld, const double* vside, const double* m,
+                                double* xout, int64_t n, int* err_dev) {
+    if (n <= 0 || n % 128 || ld % 2 || n / 128 > (1 << 20) || !err_dev || !vside) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(xout, 0xFF, (size_t)n * 8, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(trsv_lt_chain_kernel, dim3((unsigned)(n / 128)), dim3(256), 0, s, L, ld, vside, m, xout, (int)(n / 128),
+                       err_dev);
+    return hipGetLastError();
+}
+
 // ---- y = A^T x for a row-major nrows x ncols block (distributed backward solve) -----------
 // grid (column chunks, row chunks of 64); partial sums per row chunk, then a fixed-order sum
 __global__ __launch_bounds__(256) void gemv_t_partial_kernel(const double* A, int64_t ld, int64_t nrows,
@@ -399,9 +563,58 @@ __global__ void gemv_t_sum_kernel(const double* part, int64_t nchunks, int64_t n
     y[c] = s;
 }
 
+// the same partial sums for even ncols / ld: a workgroup takes 128 rows x 256 columns, a thread one column pair and
+// 64 of the rows with all of its 16-byte loads in flight at once (the access pattern of the backward solve's update:
+// 2-KiB row segments), the two halves summed in a fixed order
+__global__ __launch_bounds__(256) void gemv_t_partial2_kernel(const double* __restrict__ A, int64_t ld, int64_t nrows,
+                                                               int64_t ncols, const double* __restrict__ x, double* part) {
+    __shared__ double xs[128];
+    __shared__ double hs[256];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 128;
+    if (tid < 128) xs[tid] = (r0 + tid < nrows) ? x[r0 + tid] : 0.0;
+    __syncthreads();
+    const int half = tid >> 7;
+    const int64_t c = (int64_t)blockIdx.x * 256 + 2 * (tid & 127);
+    double a0 = 0., a1 = 0.;
+    if (c < ncols) {
+        const int64_t rb = r0 + 64 * half;
+        const double* col = A + rb * ld + c;
+        if (rb + 64 <= nrows) {
+            d2 v[64];
+#pragma unroll
+            for (int r = 0; r < 64; ++r) v[r] = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+#pragma unroll
+            for (int r = 0; r < 64; ++r) {
+                a0 = fma(v[r].x, xs[64 * half + r], a0);
+                a1 = fma(v[r].y, xs[64 * half + r], a1);
+            }
+        } else {
+            for (int r = 0; rb + r < nrows && r < 64; ++r) {
+                const d2 v = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+                a0 = fma(v.x, xs[64 * half + r], a0);
+                a1 = fma(v.y, xs[64 * half + r], a1);
+            }
+        }
+    }
+    if (half) { hs[2 * (tid & 127)] = a0; hs[2 * (tid & 127) + 1] = a1; }
+    __syncthreads();
+    if (!half && c < ncols) {
+        part[(int64_t)blockIdx.y * ncols + c] = a0 + hs[2 * tid];
+        part[(int64_t)blockIdx.y * ncols + c + 1] = a1 + hs[2 * tid + 1];
+    }
+}
+
 hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nrows, int64_t ncols,
                          const double* x, double* y, double* scratch) {
     if (ncols <= 0) return hipSuccess;
+    if (nrows > 0 && ncols % 2 == 0 && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
+        const int64_t nch = (nrows + 127) / 128;
+        hipLaunchKernelGGL(gemv_t_partial2_kernel, dim3((unsigned)((ncols + 255) / 256), (unsigned)nch), dim3(256), 0, s,
+                           A, ld, nrows, ncols, x, scratch);
+        hipLaunchKernelGGL(gemv_t_sum_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, scratch, nch, ncols, y);
+        return hipGetLastError();
+    }
     const int64_t nchunks = (nrows + 63) / 64;
     if (nchunks > 0)
         hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((unsigned)((ncols + 255) / 256), (unsigned)nchunks), dim3(256), 0, s,

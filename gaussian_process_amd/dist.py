@@ -162,10 +162,19 @@ class HipBlockOps:
                                        A.shape[0] if A is not None else 0, y.shape[0],
                                        self._p(x) if x is not None else None, self._p(y), self._p(scratch)))
 
-    def trsv_lt(self, L, b, inverted=False):
+    def trsv_lt(self, L, b, inverted=False, vside=None):
         """L^T x = b, x overwrites b (L as potrf_block leaves it).  The first call on a factored block writes the
-        inverses of its 128 x 128 diagonal blocks into their upper triangles; inverted=True says they are there."""
+        inverses of its 128 x 128 diagonal blocks into their upper triangles; inverted=True says they are there.
+        vside (n * 128 doubles, kept by the caller with the block): the one-launch form (gpmi_dev_trsv_lt_chain)."""
         n = b.shape[0]
+        if n % 128 == 0 and vside is not None:
+            x = torch.empty_like(b)
+            if getattr(self, "_err", None) is None:
+                self._err = torch.zeros(16, dtype=torch.int32, device=self.device)
+            check(self.lib.gpmi_dev_trsv_lt_chain(self._stream(), self._p(L), self._ld(L), self._p(vside), self._p(b), self._p(x),
+                                                  n, 0 if inverted else 1, self._p(self._err)))
+            b.copy_(x)
+            return
         if n % 128 == 0:
             x = torch.empty_like(b)
             check(self.lib.gpmi_dev_trsv_lt_vinv(self._stream(), self._p(L), self._ld(L), self._p(b), self._p(x), n,
@@ -236,6 +245,7 @@ class DistGP:
         self.lookahead = int(lookahead)
         self.have_factor = False
         self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
+        self._vside = {}             # local diagonal block -> its inverses' side buffer (one-launch backward solve)
         self.have_test = False
         self.stage_ms = {}
         self._prof = None            # profile(True): {key: [(start, end) events or (t0, t1) seconds]}
@@ -965,7 +975,13 @@ class DistGP:
                 # bits on every run), not G tiny launches on the latency chain of the block
                 with self._timed("alpha_solve", None):
                     rhs.sub_(allp.view(G, NB).sum(dim=0))
-                    ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs, inverted=li in self._vinv_blocks)
+                    if self._cuda():             # the one-launch backward solve keeps each block's inverses in a side buffer
+                        vs = self._vside.get(li)
+                        if vs is None:
+                            vs = self._vside[li] = self._tensor(NB * 128)
+                        ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs, inverted=li in self._vinv_blocks, vside=vs)
+                    else:
+                        ops.trsv_lt(A[li * NB:(li + 1) * NB, c0:c0 + NB], rhs, inverted=li in self._vinv_blocks)
                     self._vinv_blocks.add(li)
                     aloc[li * NB:(li + 1) * NB].copy_(rhs)
         # assemble the full vector in natural block order
@@ -979,6 +995,10 @@ class DistGP:
         else:
             recv = send
         R = recv.view(G, cmax, NB).cpu().numpy()
+        err = getattr(ops, "_err", None)
+        if err is not None and int(err[0].item()) != 0:
+            err.zero_()
+            raise RuntimeError("DistGP.alpha: the one-launch backward solve gave up waiting for a block (non-finite factor?)")
         out = np.empty(self.Np)
         for b in range(T):
             out[b * NB:(b + 1) * NB] = R[b % G, b // G]

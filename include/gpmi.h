@@ -262,7 +262,8 @@ int gpmi_dev_gemm_nt_blocks(void* stream, double* C_dev, int64_t ldc, const doub
 int gpmi_dev_logdiag_sumsq(void* stream, const double* A_dev, int64_t ld, int64_t n, const double* x_dev,
                            int64_t nx, double* out2_dev);
 /* y[c] = sum_r A[r][c] * x[r] for a row-major nrows x ncols block (fixed summation order);
- * scratch: ceil(nrows/64) * ncols doubles.  Piece of the distributed backward solve
+ * scratch: ceil(nrows/64) * ncols doubles (ncols % 2 == 0 and ld % 2 == 0 take the 16-byte-load path, which uses
+ * ceil(nrows/128) * ncols of them).  Piece of the distributed backward solve
  * (GP_regression.py:140): a rank's contribution L_jk^T alpha_j of its rows below block k. */
 int gpmi_dev_gemv_t(void* stream, const double* A_dev, int64_t ld, int64_t nrows, int64_t ncols,
                     const double* x_dev, double* y_dev, double* scratch_dev);
@@ -276,6 +277,14 @@ int gpmi_dev_trsv_lt_fused(void* stream, const double* L_dev, int64_t ld, double
  * invert == 0 on the same factored block -- each step is one matrix-vector product with it.  a5 of the multi-rank driver
  * (GP_regression.py:140). */
 int gpmi_dev_trsv_lt_vinv(void* stream, double* L_dev, int64_t ld, double* b_dev, double* x_dev, int64_t n, int invert);
+/* the same in ONE launch: the 128-column blocks are chained through the solution vector itself (x_dev is filled with a
+ * "not yet" NaN pattern, a block's consumers poll the entries they need), so no launch gap and no chip-wide update sits
+ * between two blocks.  vside_dev: n * 128 doubles owned by the caller; invert != 0 first fills it with the inverses of the
+ * 128 x 128 diagonal blocks (row-major, one launch; also written into the blocks' upper triangles as above), later calls
+ * on the same factored block pass 0 and the same buffer.  m_dev is only read; x_dev must not alias it.  err_dev: one int
+ * the kernel sets to 1 if a poll gave up (non-finite factor); zero it before the call.  a5 (GP_regression.py:140). */
+int gpmi_dev_trsv_lt_chain(void* stream, double* L_dev, int64_t ld, double* vside_dev, const double* m_dev, double* x_dev,
+                           int64_t n, int invert, int* err_dev);
 /* on != 0: the block primitives called from this thread run beside a trailing update on another stream (lookahead)
  * and use their small-LDS forms, which fit on a CU next to an update workgroup; same results.  0 switches back. */
 int gpmi_dev_set_concurrent(int on);

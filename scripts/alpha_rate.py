@@ -1,5 +1,6 @@
 """a5 alone: the backward solve L^T alpha = m at several sizes (ms, GB/s over 8 N (N+1) / 2 bytes), with the
-inverted 128 x 128 diagonal blocks (option trsv_vinv = 1: first call after a fit pays the inversion launch) and with
+inverted 128 x 128 diagonal blocks (option trsv_vinv = 1: one launch per block; 2: ONE launch, column blocks chained through the
+solution vector; the first call after a fit pays the inversion launch) and with
 the 16 x 16 rounds of the second generation (trsv_vinv = 0)."""
 import os, sys, time
 import numpy as np
@@ -11,7 +12,7 @@ ctx = GPContext(0)
 for N in [int(a) for a in sys.argv[1:]] or [4096, 16384, 65536]:
     X, y, _ = O.synthetic_problem(N, 8, 4)
     ref = None
-    for vinv in (0, 1):
+    for vinv in (0, 1, 2):
         ctx.set_option("trsv_vinv", vinv)
         first = []
         for _ in range(3):
