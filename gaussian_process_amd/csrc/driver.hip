@@ -140,7 +140,10 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     // below ~12k columns the two-stream choreography costs more than the panel it hides
     const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
     hipStream_t sp_ = la ? c->pstream : sm;
-    GemmShallowScope shallow(la);                 // panel-internal updates run beside the trailing update
+    // panel kernels beside the trailing update use their small-LDS forms -- while there IS a trailing update of some length
+    // to run beside: once the columns right of the panel are fewer than c->shallow_min, part (b) of a step is over long
+    // before the panel chain is, and the one-launch forms (which then find empty CUs) are the shorter chain
+    GemmShallowScope shallow(la);
     // (a) on the panel stream pays at mid sizes (N = 16384: -4 %, 32768: -1 %), where a launch's tail and the
     // panel chain are a visible share of a step; at the headline size it is worth 0.4 % and would put two
     // trailing-update launches in flight at once, which makes "time per launch" (the roofline figure) ambiguous
@@ -179,7 +182,10 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     for (size_t step = 0; step < widths.size(); ++step) {
         const int64_t nb = widths[step];
         size_t sp = c->span_begin(slot_p, sp_);
-        e = panel_factor(sp_, A + k * ld + k, ld, nb, nrows - k, k, info);
+        {
+            GemmShallowScope panel_forms(la && ncols - k >= c->shallow_min, la, true);
+            e = panel_factor(sp_, A + k * ld + k, ld, nb, nrows - k, k, info);
+        }
         c->span_end(sp, sp_);
         if (e != hipSuccess) return e;
         if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;

@@ -668,8 +668,9 @@ constexpr int SM_T = 64;                                   // tile edge
 constexpr int SM_STAGE_SLOTS = (SM_T + SM_T) * 8;          // 16-byte slots per stage (A then B): 16 KiB
 static thread_local int t_small_shallow = 0;
 static thread_local int t_two_streams = 0;
-GemmShallowScope::GemmShallowScope(bool on, bool two_streams) : prev(t_small_shallow), prev_two(t_two_streams) {
+GemmShallowScope::GemmShallowScope(bool on, bool two_streams, bool exact) : prev(t_small_shallow), prev_two(t_two_streams) {
     if (on) t_small_shallow = 1;
+    else if (exact) t_small_shallow = 0;
     if (on || two_streams) t_two_streams = 1;
 }
 GemmShallowScope::~GemmShallowScope() { t_small_shallow = prev; t_two_streams = prev_two; }

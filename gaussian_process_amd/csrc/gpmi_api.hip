@@ -93,6 +93,9 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "shallow_min")) {
+        if (value < 0) return fail_arg("shallow_min must be >= 0");
+        c->shallow_min = value;
     } else if (!strcmp(name, "lanes")) {
         if (value < 0 || value > 8) return fail_arg("lanes must be 0 (by size) .. 8");
         c->lanes = (int)value;

@@ -95,10 +95,11 @@ struct gpmi_ctx {
     hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
     // options
     int64_t nb = 0;         // outer block width of the Cholesky (multiple of 128); 0 = by size
-    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 49152 ? 2048 : ncols >= 12288 ? 1024 : 512); }
+    int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 32768 ? 2048 : ncols >= 12288 ? 1024 : 512); }
     int64_t ld_pad = 544;   // doubles added to every leading dimension
     int timing = 1;
     int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
+    int64_t shallow_min = 6144; // under lookahead, panels with fewer columns left than this use the one-launch panel kernels (0: never)
     int lanes = 0;          // gpmi_lml_batch: factorisations in flight (0 = by size)
     std::vector<gpmi_ctx*> lane_ctx;   // the extra lanes (own streams and workspaces), created on demand
     int ramp = 0;           // block-width schedule, bit mask: 1 ramp up at the start, 2 half width over the last blocks (count in bits 4.., default 3),

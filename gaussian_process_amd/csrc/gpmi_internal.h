@@ -97,7 +97,8 @@ bool gemm_two_streams_active();
 // may take the whole chip for its whole length (the persistent GEMM form stays off)
 struct GemmShallowScope {
     int prev, prev_two;
-    explicit GemmShallowScope(bool on, bool two_streams = false);
+    // exact: `on` == false switches the small-LDS forms OFF for the scope (default: an enclosing scope's setting stays)
+    explicit GemmShallowScope(bool on, bool two_streams = false, bool exact = false);
     ~GemmShallowScope();
 };
 hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a);
@@ -115,6 +116,7 @@ hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double
 // ---- panel_mfma.hip --------------------------------------------------------
 // Cholesky of one 128 x 128 diagonal block in place (lower), one workgroup, MFMA updates.
 hipError_t launch_potrf128(hipStream_t s, double* A, int64_t ld, int64_t col_offset, int64_t* info_dev);
+
 // X (m x 128) <- X * L^-T, L 128 x 128 lower; m multiple of 128; on the matrix pipe.
 hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m);
 
