@@ -34,7 +34,8 @@ except (OSError, KeyError, ValueError):
     pass
 
 # nominal MI355X peaks; `peaks_probe` in the output is what this
-# box sustains on bare probe kernels in this run
+# box sustains on bare probe kernels in this run (register-only MFMA loop, streaming loads / stores), measured after the
+# timed region; every roofline block carries its fraction of both
 PEAK_FP64_MFMA_TFLOPS = 78.6     # 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz
 PEAK_HBM_GBPS = 8000.0
 # north_star targets
@@ -42,9 +43,43 @@ TARGET_TRAIL_FRAC = 0.40
 TARGET_KBUILD_FRAC = 0.60
 TARGET_SPEEDUP_8 = 6.0
 TARGET_MEAN_TOL = 1e-8
-# the committed rocprofv3 PMC passes `roofline.traffic` is read from (same command, N=65536 n=4096)
-TRAFFIC_PROFILE = os.path.join("profiles", "r02c_roofline_traffic.json")
-TRAFFIC_PROFILE_FALLBACK = os.path.join("profiles", "r02_roofline_traffic.json")
+# the committed rocprofv3 PMC passes `roofline.traffic` is read from (same command, N=65536 n=4096); the file records the
+# SHA-256 of the kernel's source at collection time and the line says "stale" when the source has changed since
+TRAFFIC_PROFILES = [os.path.join("profiles", f) for f in ("r03_roofline_traffic.json", "r02c_roofline_traffic.json",
+                                                          "r02_roofline_traffic.json")]
+TRAFFIC_KERNEL_SOURCE = os.path.join("gaussian_process_amd", "csrc", "gemm_dma.hip")
+# K build: vector instructions per matrix element at d = 8 (23 fixed by NumPy's summation order + 13 of the exp),
+# rocprofv3 SQ_INSTS_VALU / elements in profiles/r03_pmc_kbuild_summary.txt
+KBUILD_VALU_PER_ELEMENT_D8 = 36.0
+
+
+def source_sha256(rel):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()
+    except OSError:
+        return None
+
+
+def probe_peaks(ctx):
+    """What this box sustains on bare kernels, right now (a few hundred ms, outside the timed region): the fp64 MFMA
+    issue rate with the shader clock it holds meanwhile, and streaming HBM reads / writes over 4 GiB."""
+    out = {}
+    best, shape = (0.0, 0.0, 0.0), None
+    for wps, nacc in ((4, 4), (4, 8), (2, 8), (2, 16)):       # waves per SIMD, independent accumulators per wave
+        r = ctx.probe_mfma_f64_ex(wps, nacc, 8192)
+        if r[0] > best[0]:
+            best, shape = r, (wps, nacc)
+    out["fp64_mfma_tflops"], out["mfma_clock_ghz"], out["cycles_per_mfma_per_simd"] = best
+    out["mfma_shape"] = {"waves_per_simd": shape[0], "accumulators_per_wave": shape[1]}
+    nbytes = 4 << 30
+    out["hbm_write_gbps"] = max(ctx.probe_hbm_ex(nbytes, mode, blocks) for mode in (0, 2, 3) for blocks in (4096, 16384))
+    out["hbm_read_gbps"] = max(ctx.probe_hbm_ex(nbytes, 4, blocks) for blocks in (2048, 4096, 65536))
+    out["note"] = ("register-only v_mfma_f64_16x16x4_f64 loop, one workgroup per CU (best of four shapes; a wave cannot issue "
+                   "these back to back at the pipe's rate, so the probe needs 4 waves per SIMD where the GEMM reaches its "
+                   "rate with 2) and 16-byte streaming stores / loads over 4 GiB (best of several grid shapes), run after "
+                   "the timed steps on the same context")
+    return out
 
 
 def algorithmic_flops(N, n):
@@ -347,13 +382,17 @@ def main():
             if N == 65536 and n == 4096:
                 # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same
                 # command (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; scripts/rocpd_extract.py traffic)
-                for rel in (TRAFFIC_PROFILE, TRAFFIC_PROFILE_FALLBACK):
+                for rel in TRAFFIC_PROFILES:
                     tpath = os.path.join(ROOT, rel)
                     if os.path.exists(tpath):
                         tj = json.load(open(tpath))
                         traffic = tj.get("traffic_bytes_per_launch")
+                        sha_then, sha_now = tj.get("kernel_source_sha256"), source_sha256(TRAFFIC_KERNEL_SOURCE)
                         traffic_src = {"file": rel, "git": tj.get("git"), "measured": "separate rocprofv3 --pmc passes, "
-                                       "not in this run"}
+                                       "not in this run", "kernel_source": TRAFFIC_KERNEL_SOURCE,
+                                       "stale": (sha_then != sha_now) if sha_then and sha_now else None,
+                                       "stale_means": "the kernel's source file has changed since the counters were "
+                                                      "collected (SHA-256 recorded in the profile); null: unknown"}
                         break
             out["roofline"] = {
                 "kernel": "chol_trailing_update_dma_kernel (Cholesky trailing update: 128x128 tile, 8 waves x 2x4 "
@@ -377,6 +416,18 @@ def main():
                                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": frac,
                                      "bytes": kbytes, "note": "lower tiles incl. diagonal"}
                 targets["kbuild_hbm_frac"] = {"target": TARGET_KBUILD_FRAC, "achieved": frac, "met": frac >= TARGET_KBUILD_FRAC}
+                if d == 8:
+                    # the kernel is bound by vector-instruction issue, not by HBM: 36 fp64-rate instructions per element
+                    # (23 of them NumPy's summation order, which bit-exact parity fixes) on 1024 SIMDs of 16 lanes
+                    elems = 128.0 * 128 * T * (T + 1) / 2
+                    for ghz in (2.4, 1.8):
+                        ceil_gbps = 1024 * 16 * ghz * 1e9 / KBUILD_VALU_PER_ELEMENT_D8 * 8 / 1e9
+                        out["kbuild_hbm"]["valu_ceiling_gbps_at_%.1fGHz" % ghz] = ceil_gbps
+                    out["kbuild_hbm"]["valu_instructions_per_element"] = KBUILD_VALU_PER_ELEMENT_D8
+                    out["kbuild_hbm"]["valu_issue_ghz_implied"] = elems * KBUILD_VALU_PER_ELEMENT_D8 / (1024 * 16) / (kb * 1e-3) / 1e9
+                    out["kbuild_hbm"]["bound_note"] = ("VALU-issue bound: elements x 36 instructions / (1024 SIMDs x 16 lanes) / time "
+                                                       "= the shader clock the kernel would need if it did nothing but issue them "
+                                                       "(valu_issue_ghz_implied); the chip holds ~1.8-2.1 GHz on this fp64 + store mix")
             al = stage.get("alpha", 0.0) / k
             if al > 0:
                 abytes = 8.0 * N * (N + 1) / 2
@@ -390,6 +441,20 @@ def main():
                                        "unit": "TFLOP/s", "frac": vflops / (sv * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
                                        "flops": vflops, "ms": sv,
                                        "note": "a7: v = L^-1 K_s as a blocked sweep (trsm128 leaves + MFMA updates), N^2 n flop"}
+            # the peaks this box sustains on bare probe kernels, and every fraction against them as well
+            try:
+                pk = probe_peaks(ctx)
+                out["peaks_probe"] = pk
+                if pk.get("fp64_mfma_tflops", 0) > 0:
+                    for key in ("roofline", "solve_v_mfma"):
+                        if key in out:
+                            out[key]["frac_of_probed"] = out[key]["achieved"] / pk["fp64_mfma_tflops"]
+                if "kbuild_hbm" in out and pk.get("hbm_write_gbps", 0) > 0:
+                    out["kbuild_hbm"]["frac_of_probed"] = out["kbuild_hbm"]["achieved"] / pk["hbm_write_gbps"]
+                if "alpha_hbm" in out and pk.get("hbm_read_gbps", 0) > 0:
+                    out["alpha_hbm"]["frac_of_probed"] = out["alpha_hbm"]["achieved"] / pk["hbm_read_gbps"]
+            except Exception as e:      # never cost the bench line
+                out["peaks_probe"] = {"error": str(e)}
             # the peaks as this box reports them (hipDeviceProp_t), next to the nominal ones the fractions are priced against
             try:
                 di = ctx.device_info()

@@ -97,12 +97,14 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
         # the covariance row-block partitioned over the ranks of the node (dist.py); every rank makes this call
         # with the same arguments and gets the same results; the normals of :155 come from each rank's own
         # np.random (seed them alike for identical samples)
-        if kernel_choice != 'rbf':
-            raise ValueError("the multi-GPU path covers the squared-exponential kernel (kernel_choice='rbf')")
-        from ._lib import scalar
-        lml = gp.fit(X_train, y_train, sigma, scalar(l, "l"), noise_var)
-        mu_post, stand_devi = gp.predict(X_test, want_sd=True)
-        L_ = gp.post_chol(jitter)
+        try:
+            sg, ll = _select_kernel(gp, kernel_choice, l, sigma)      # :125-136, the same three choices on every path
+            from ._lib import scalar
+            lml = gp.fit(X_train, y_train, sg, scalar(ll, "l"), noise_var)
+            mu_post, stand_devi = gp.predict(X_test, want_sd=True)
+            L_ = gp.post_chol(jitter)
+        finally:
+            gp.set_kernel('rbf')
         f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(mu_post.shape[0], num_fun)))
         if return_lml:
             return mu_post, stand_devi, f_post_fun, np.float64(lml)

@@ -65,6 +65,8 @@ SIGNATURES = {
     "gpmi_probe_panel": [_vp, C.c_int, _i64, C.c_int, _dp, C.POINTER(C.c_uint64)],
     "gpmi_dev_rbf_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, C.c_double, _vp, _i64],
     "gpmi_dev_rbf_cross": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _vp, _i64],
+    "gpmi_dev_cov_rows": [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, _vp, _i64],
+    "gpmi_dev_cov_cross": [_vp, C.c_int, _dp, C.c_int, _vp, _i64, _vp, _i64, _i64, _i64, C.c_int, _i64, _i64, _vp, _i64],
     "gpmi_dev_potrf_block": [_vp, _vp, _i64, _i64, _i64, _vp],
     "gpmi_dev_trsm_block": [_vp, _vp, _i64, _vp, _i64, _i64, _i64],
     "gpmi_dev_gemm_nt": [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int, _i64],

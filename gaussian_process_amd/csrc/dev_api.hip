@@ -35,6 +35,66 @@ int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const doub
     return GPMI_OK;
 }
 
+// covariance parameters of the gpmi_dev_cov_* entry points, as gpmi_set_kernel / gpmi_set_kernel_params take them
+static int dev_cov_args(RbfArgs& r, int kind, const double* params, int nparams, const char* who) {
+    static const int want[4] = {2, 1, 2, 11};
+    if (kind < 0 || kind > 3) return fail_arg("gpmi_dev_cov: kind must be 0 (rbf), 1 (linear), 2 (periodic) or 3 (CO2 composite)");
+    if (!params || nparams != want[kind]) return fail_arg("gpmi_dev_cov: kinds 0 / 1 / 2 / 3 take 2 / 1 / 2 / 11 parameters");
+    (void)who;
+    r.kind = kind;
+    if (kind == 0) {
+        if (!(params[1] != 0.0)) return fail_arg("gpmi_dev_cov: ell must be non-zero");
+        r.coef = -.5 * (1 / (params[1] * params[1])); r.sig2 = params[0] * params[0];
+    } else if (kind == 1) {
+        r.kp0 = params[0];
+    } else if (kind == 2) {
+        if (!(params[0] != 0.0) || !(params[1] != 0.0)) return fail_arg("gpmi_dev_cov: period and lengthscale must be non-zero");
+        if (r.d != 1) return fail_arg("gpmi_dev_cov: the periodic kernel is 1-D only (GP_regression.py:48)");
+        r.kp0 = params[0]; r.kp1 = params[1];
+    } else {
+        for (int i = 0; i < 11; ++i) r.kpv[i] = params[i];
+    }
+    return GPMI_OK;
+}
+
+// gpmi_dev_rbf_rows for any of the reference's covariance functions (f4 on the partitioned path): rows row0 .. of
+// K(X, X) + noise_var * I, lower tiles, identity padding.  kind / params as gpmi_set_kernel (0: sigma, l; 1: c;
+// 2: period, l) and gpmi_set_kernel_params (3: the 11 hyper-parameters of CO2_example.py's covariance_function, whose
+// kernel_4 adds theta_11^2 on the diagonal of a square matrix).
+int gpmi_dev_cov_rows(void* stream, int kind, const double* params, int nparams, const double* X_dev, int64_t N, int64_t d,
+                      int64_t row0, int64_t nrows, int64_t ncols, double noise_var, double* out_dev, int64_t ld) {
+    if (!X_dev || !out_dev) return fail_arg("gpmi_dev_cov_rows: null pointer");
+    if (nrows % TILE || ncols % TILE || row0 % TILE || ld < ncols || ld % 2)
+        return fail_arg("gpmi_dev_cov_rows: sizes must be multiples of 128");
+    RbfArgs r;
+    r.A = r.B = X_dev; r.nA = r.nB = N; r.d = d; r.row0 = row0; r.nrows = nrows; r.ncols = ncols;
+    const int rc = dev_cov_args(r, kind, params, nparams, "gpmi_dev_cov_rows");
+    if (rc) return rc;
+    r.diag_add = noise_var; r.symmetric = 1; r.delta_square = 1;
+    r.out = out_dev; r.ld = ld;
+    HIP_TRY(launch_rbf((hipStream_t)stream, r));
+    return GPMI_OK;
+}
+
+// gpmi_dev_rbf_cross likewise: out[i][j] = k(Xs[i], Xcols[j]) for a WINDOW of the column inputs that starts at input
+// col0 of the full set; square != 0 says the full cross matrix is square (n == N), in which case the composite kernel's
+// delta term lands on i == col0 + j (CO2_example.py:58-62).  Rows >= n and columns >= ncols_real are zero.
+int gpmi_dev_cov_cross(void* stream, int kind, const double* params, int nparams, const double* Xs_dev, int64_t n,
+                       const double* Xcols_dev, int64_t ncols_real, int64_t d, int64_t col0, int square, int64_t nrows,
+                       int64_t ncols, double* out_dev, int64_t ld) {
+    if (!Xs_dev || !Xcols_dev || !out_dev) return fail_arg("gpmi_dev_cov_cross: null pointer");
+    if (nrows % TILE || ncols % TILE || ld < ncols || ld % 2 || col0 < 0)
+        return fail_arg("gpmi_dev_cov_cross: sizes must be multiples of 128");
+    RbfArgs r;
+    r.A = Xs_dev; r.B = Xcols_dev; r.nA = n; r.nB = ncols_real > 0 ? ncols_real : 0; r.d = d; r.row0 = 0; r.nrows = nrows; r.ncols = ncols;
+    const int rc = dev_cov_args(r, kind, params, nparams, "gpmi_dev_cov_cross");
+    if (rc) return rc;
+    r.diag_add = 0.; r.symmetric = 0; r.delta_square = square ? 1 : 0; r.delta_col0 = col0;
+    r.out = out_dev; r.ld = ld;
+    HIP_TRY(launch_rbf((hipStream_t)stream, r));
+    return GPMI_OK;
+}
+
 int gpmi_dev_potrf_block(void* stream, double* A_dev, int64_t ld, int64_t nb, int64_t col_offset,
                          int64_t* info_dev) {
     if (!A_dev || !info_dev) return fail_arg("gpmi_dev_potrf_block: null pointer");

@@ -914,9 +914,10 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     // CU for the panel kernels of the other stream, which would then wait for the whole launch instead of a tile
     // (lookahead with both forms: N = 16384 fit + predict 39.8 against 42.9 ms)
     if (tn.gemm_persist && tn.gemm_dma_waves == 8 && !p.dbg && p.nchunks >= 16 && !gemm_two_streams_active()) {
+        // no pool (its allocation or the opt-in failed, or an unusual device): the persistent form is an optimisation,
+        // the per-tile launch below computes the same bits
         PersistPool* pool = persist_pool();
-        if (!pool) return hipErrorOutOfMemory;
-        if (nblocks >= 2 * pool->groups) {
+        if (pool && nblocks >= 2 * pool->groups) {
             p.slot = pool->next();
             constexpr size_t ldsp = lds + 16;          // ring + mailbox
             if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);

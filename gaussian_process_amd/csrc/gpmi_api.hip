@@ -100,6 +100,9 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         if (value < 0 || value > 8) return fail_arg("lanes must be 0 (by size) .. 8");
         c->lanes = (int)value;
     } else if (!strcmp(name, "ramp")) {
+        // bit mask: 1 ramp up, 2 half width over the last blocks, 4 quarter width for the last block, bits 4.. = how many
+        // blocks count as "last" (0: three)
+        if (value < 0 || (value & 8) || (value >> 4) > 64) return fail_arg("ramp: bits 0-2 and a tail count of at most 64 in bits 4..");
         c->ramp = (int)value;
     } else if (!strcmp(name, "gemm_small_tiles")) {
         c->tune.gemm_small_tiles = value ? 1 : 0;

@@ -108,7 +108,11 @@ struct gpmi_ctx {
     // training set / factor
     int64_t N = 0, d = 0, Np = 0, ldA = 0, Mp = 0;
     bool have_train = false, have_factor = false;
-    bool have_vinv = false;  // the resident factor's 128 x 128 diagonal blocks carry their full inverses (launch_vinv128; set by the first backward solve)
+    // The resident factor's 128 x 128 diagonal blocks carry their full inverses (launch_vinv128; set by the first backward
+    // solve).  OWNERSHIP: from then on the strict block-upper 16 x 16 tiles of every diagonal block of A hold L_kk^-T, not
+    // zeros and not K: nothing but the backward-solve kernels may read them (every other consumer of a diagonal block masks
+    // to the lower triangle; gpmi_get_factor_block zeroes the upper triangle on the way out).
+    bool have_vinv = false;
     int factor_fused = 1;    // the resident factor came from the fused panel kernels: its diagonal 16 x 16 tiles carry
                              // their inverses above the diagonal, which trsm128 reads (panel_mfma.hip)
     double sig2 = 1.0, coef = -0.5;

@@ -142,6 +142,7 @@ struct RbfArgs {
     double kp0 = 0., kp1 = 0.;
     double kpv[11] = {0., 0., 0., 0., 0., 0., 0., 0., 0., 0., 0.};
     int delta_square = 0;     // kind 3: the reference's output is square -> kernel_4 adds theta_11^2 * eye (:58-59)
+    int64_t delta_col0 = 0;   // ... at row == col + delta_col0 (B is a window of the column inputs starting there)
     // upper bound of |a_i - b_j|^2 over the whole launch (from the inputs' bounding boxes), or < 0
     // when unknown: lets the squared-exponential build skip its per-wave exp domain test
     double max_sq = -1.0;
@@ -205,7 +206,7 @@ hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0
                           int64_t c0, int64_t c1, double* out, int lower_only);
 
 // ---- probes ----------------------------------------------------------------
-hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks, int nacc,
+hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int cus, int waves_per_simd, int nacc,
                              unsigned long long* clk);
 hipError_t launch_probe_write(hipStream_t s, double* buf, int64_t n_doubles, int mode, int blocks, double* sink);
 

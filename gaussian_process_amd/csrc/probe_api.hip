@@ -9,22 +9,23 @@ extern "C" {
 // out[2] = shader cycles per MFMA per SIMD
 int gpmi_probe_mfma_f64_ex(gpmi_ctx* c, int blocks_per_cu, int nacc, int iters, double* out) {
     if (!c || !out) return fail_arg("gpmi_probe_mfma_f64_ex: null argument");
-    if (blocks_per_cu < 1 || blocks_per_cu > 8 || iters < 1) return fail_arg("gpmi_probe_mfma_f64_ex: bad argument");
+    if (blocks_per_cu < 1 || blocks_per_cu > 4 || iters < 1) return fail_arg("gpmi_probe_mfma_f64_ex: waves per SIMD must be 1 .. 4");
     if (nacc != 4 && nacc != 8 && nacc != 16) return fail_arg("gpmi_probe_mfma_f64_ex: nacc must be 4, 8 or 16");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(c->red.ensure(16 * 8));
     hipStream_t s = c->stream;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
-    const int blocks = prop.multiProcessorCount * blocks_per_cu;
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * blocks_per_cu;        // 4-wave groups in flight (for the flop count below)
     double* sink = c->red.as<double>();
     unsigned long long* clk = reinterpret_cast<unsigned long long*>(sink + 8);
-    HIP_TRY(launch_probe_mfma(s, sink, 64, blocks, nacc, clk));   // warm-up
+    HIP_TRY(launch_probe_mfma(s, sink, 64, cus, blocks_per_cu, nacc, clk));   // warm-up
     hipEvent_t a, b;
     HIP_TRY(hipEventCreate(&a));
     HIP_TRY(hipEventCreate(&b));
     HIP_TRY(hipEventRecord(a, s));
-    HIP_TRY(launch_probe_mfma(s, sink, iters, blocks, nacc, clk));
+    HIP_TRY(launch_probe_mfma(s, sink, iters, cus, blocks_per_cu, nacc, clk));
     HIP_TRY(hipEventRecord(b, s));
     HIP_TRY(hipEventSynchronize(b));
     float ms = 0.f;

@@ -45,6 +45,7 @@ struct RbfDev {
     double kp0, kp1;
     double kpv[11];        // kind 3: theta_1 .. theta_11 of the CO2 composite kernel
     int delta_square;      // kind 3: the output is square, so kernel_4 adds theta_11^2 on row == col
+    int64_t delta_col0;    // ... where "col" counts from this offset (B is a window of the column inputs: multi-rank predict)
     int nocheck;           // host-proved: every exp argument of this launch lies in [-700, 0]
     int strip;             // rbf_regs_kernel: row tiles per work item
     int nitems;            // rbf_regs_kernel: strips x column tiles
@@ -327,8 +328,8 @@ __global__ __launch_bounds__(256) void rbf_kernel(const RbfDev p) {
                 const double* bc = &Bs[2 * cp];
                 double v0 = 0., v1 = 0.;
                 if (gr < p.nA) {
-                    if (gc < p.nB) v0 = cov_other_acc(p, [&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT]; }, gr == gc);
-                    if (gc + 1 < p.nB) v1 = cov_other_acc(p, [&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT + 1]; }, gr == gc + 1);
+                    if (gc < p.nB) v0 = cov_other_acc(p, [&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT]; }, gr == gc + p.delta_col0);
+                    if (gc + 1 < p.nB) v1 = cov_other_acc(p, [&](int k) { return ar[k]; }, [&](int k) { return bc[k * RT + 1]; }, gr == gc + 1 + p.delta_col0);
                 }
                 cov_store(p, gr, gc, v0, v1, out0 + (int64_t)r * p.ld);
             }
@@ -513,14 +514,15 @@ __global__ __launch_bounds__(256) void cov_other_kernel(const RbfDev p) {
         const int64_t gr = grow0 + 32 * rg + r;
         double v0 = 0., v1 = 0.;
         if (gr < p.nA) {
-            if (gc < p.nB) v0 = cov_other(p, p.A + gr * d, p.B + gc * d, gr == gc);
-            if (gc + 1 < p.nB) v1 = cov_other(p, p.A + gr * d, p.B + (gc + 1) * d, gr == gc + 1);
+            if (gc < p.nB) v0 = cov_other(p, p.A + gr * d, p.B + gc * d, gr == gc + p.delta_col0);
+            if (gc + 1 < p.nB) v1 = cov_other(p, p.A + gr * d, p.B + (gc + 1) * d, gr == gc + 1 + p.delta_col0);
         }
         cov_store(p, gr, gc, v0, v1, p.out + ((int64_t)ti * RT + 32 * rg + r) * p.ld + gc);
     }
 }
 
-// 2^(j/2048) rounded to double from an extended-precision evaluation, uploaded once per device
+// 2^(j / EXP_TAB), j = 0 .. EXP_TAB - 1 (EXP_TAB = 4096), rounded to double from an extended-precision evaluation,
+// uploaded once per device
 static hipError_t exp_table_ready() {
     static PerDeviceOnce once;
     return once.run([]() -> hipError_t {
@@ -542,6 +544,7 @@ hipError_t launch_rbf(hipStream_t s, const RbfArgs& a) {
     p.kind = a.kind; p.kp0 = a.kp0; p.kp1 = a.kp1;
     for (int i = 0; i < 11; ++i) p.kpv[i] = a.kpv[i];
     p.delta_square = a.delta_square;
+    p.delta_col0 = a.delta_col0;
     // coef <= 0 and max_sq bounds every squared distance of this launch (NaN / unknown fail the test)
     p.nocheck = (a.max_sq >= 0.0 && a.coef <= 0.0 && a.coef * a.max_sq * 1.000001 >= -690.0) ? 1 : 0;
     if (a.kind < 0 || a.kind > 3 || (a.kind == 2 && a.d != 1)) return hipErrorInvalidValue;

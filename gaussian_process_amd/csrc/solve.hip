@@ -693,8 +693,11 @@ hipError_t launch_extract(hipStream_t s, const double* A, int64_t ld, int64_t r0
 // ---- probes ----------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// One workgroup per CU (the launch asks for 96 KiB of LDS it never touches, so that two cannot share a CU and none
+// stays empty: with several small workgroups per CU the dispatcher's placement is uneven and the slowest CU sets the
+// time), blockDim.x / 256 waves per SIMD.
 template <int NACC>
-__global__ __launch_bounds__(256) void probe_mfma_kernel(double* sink, int iters, unsigned long long* clk) {
+__global__ __launch_bounds__(1024) void probe_mfma_kernel(double* sink, int iters, unsigned long long* clk) {
     d4 acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = d4{0., 0., 0., 0.};
@@ -715,12 +718,22 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(double* sink, int iters
     if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
 }
 
-hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int blocks, int nacc,
+hipError_t launch_probe_mfma(hipStream_t s, double* sink, int iters, int cus, int waves_per_simd, int nacc,
                              unsigned long long* clk) {
+    constexpr int lds = 96 * 1024;
+    static PerDeviceOnce once;
+    const hipError_t ea = once.run([&]() -> hipError_t {
+        hipError_t e = hipFuncSetAttribute((const void*)probe_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)probe_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)probe_mfma_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        return e;
+    });
+    if (ea != hipSuccess) return ea;
+    const dim3 g((unsigned)cus), b((unsigned)(256 * waves_per_simd));
     switch (nacc) {
-        case 4: hipLaunchKernelGGL(probe_mfma_kernel<4>, dim3(blocks), dim3(256), 0, s, sink, iters, clk); break;
-        case 16: hipLaunchKernelGGL(probe_mfma_kernel<16>, dim3(blocks), dim3(256), 0, s, sink, iters, clk); break;
-        default: hipLaunchKernelGGL(probe_mfma_kernel<8>, dim3(blocks), dim3(256), 0, s, sink, iters, clk); break;
+        case 4: hipLaunchKernelGGL(probe_mfma_kernel<4>, g, b, lds, s, sink, iters, clk); break;
+        case 16: hipLaunchKernelGGL(probe_mfma_kernel<16>, g, b, lds, s, sink, iters, clk); break;
+        default: hipLaunchKernelGGL(probe_mfma_kernel<8>, g, b, lds, s, sink, iters, clk); break;
     }
     return hipGetLastError();
 }

@@ -111,6 +111,19 @@ class HipBlockOps:
         check(self.lib.gpmi_dev_rbf_cross(self._stream(), self._p(Xs), n, self._p(Xcols), max(ncols_real, 0), d,
                                           0, nrows, ncols, float(sigma), float(ell), self._p(out), self._ld(out)))
 
+    def cov_rows(self, kind, params, X, N, d, row0, nrows, ncols, noise_var, out):
+        """rbf_rows for any covariance function: kind 0 rbf (sigma, l), 1 lin (c), 2 per (p, l), 3 CO2 composite (11)"""
+        pr = np.ascontiguousarray(params, dtype=np.float64)
+        check(self.lib.gpmi_dev_cov_rows(self._stream(), int(kind), pr.ctypes.data_as(C.POINTER(C.c_double)), pr.shape[0],
+                                         self._p(X), N, d, row0, nrows, ncols, float(noise_var), self._p(out), self._ld(out)))
+
+    def cov_cross(self, kind, params, Xs, n, Xcols, ncols_real, d, col0, square, nrows, ncols, out):
+        """rbf_cross likewise; Xcols is a window of the column inputs starting at input col0, square: n == N"""
+        pr = np.ascontiguousarray(params, dtype=np.float64)
+        check(self.lib.gpmi_dev_cov_cross(self._stream(), int(kind), pr.ctypes.data_as(C.POINTER(C.c_double)), pr.shape[0],
+                                          self._p(Xs), n, self._p(Xcols), max(ncols_real, 0), d, int(col0), 1 if square else 0,
+                                          nrows, ncols, self._p(out), self._ld(out)))
+
     def potrf_block(self, A, col_offset, info):
         check(self.lib.gpmi_dev_potrf_block(self._stream(), self._p(A), self._ld(A), A.shape[0], col_offset,
                                             self._p(info)))
@@ -246,6 +259,7 @@ class DistGP:
         self.have_factor = False
         self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
         self._vside = {}             # local diagonal block -> its inverses' side buffer (one-launch backward solve)
+        self._kind = None            # covariance function other than the squared exponential: (kind number, parameters)
         self.have_test = False
         self.stage_ms = {}
         self._prof = None            # profile(True): {key: [(start, end) events or (t0, t1) seconds]}
@@ -291,6 +305,64 @@ class DistGP:
 
     def _tensor(self, *shape, dtype=torch.float64):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    # ------------------------------------------------------------------ covariance function (f4)
+    KINDS = {"rbf": 0, "lin": 1, "per": 2, "co2": 3}
+
+    def set_kernel(self, kind, p0=0.0, p1=0.0):
+        """Covariance function of the following fits (kernel_choice of prediction(), GP_regression.py:125-136; 'co2':
+        CO2_example.py:66-90 with p0 = its 11 hyper-parameters) -- the same choices as GPContext.set_kernel.  'rbf' takes
+        its sigma and l from factorize()."""
+        if kind not in self.KINDS:
+            raise ValueError("kernel must be 'rbf', 'lin', 'per' or 'co2', got %r" % (kind,))
+        if kind == "rbf":
+            new = None
+        elif kind == "lin":
+            new = (1, np.array([float(p0)]))
+        elif kind == "per":
+            if not (float(p0) != 0.0 and float(p1) != 0.0):
+                raise ValueError("period and lengthscale must be non-zero")
+            new = (2, np.array([float(p0), float(p1)]))
+        else:
+            th = np.ascontiguousarray(np.asarray(p0, dtype=np.float64).reshape(-1))
+            if th.shape[0] != 11:
+                raise ValueError("the CO2 composite kernel takes 11 hyper-parameters")
+            new = (3, th)
+        same = (new is None and self._kind is None) or (
+            new is not None and self._kind is not None and new[0] == self._kind[0] and np.array_equal(new[1], self._kind[1]))
+        self._kind = new
+        if not same:                      # a resident factor belongs to the covariance function it was built with
+            self.have_factor = False
+            self.have_v = False
+
+    def _cov_rows(self, X, N, row0, nrows, ncols, noise_var, out):
+        if self._kind is None:
+            self.ops.rbf_rows(X, N, self.d, row0, nrows, ncols, self.sigma, self.ell, noise_var, out)
+        else:
+            self.ops.cov_rows(self._kind[0], self._kind[1], X, N, self.d, row0, nrows, ncols, noise_var, out)
+
+    def _cov_cross(self, Xs, n, Xcols, ncols_real, col0, nrows, ncols, out):
+        if self._kind is None:
+            self.ops.rbf_cross(Xs, n, Xcols, ncols_real, self.d, nrows, ncols, self.sigma, self.ell, out)
+        else:
+            self.ops.cov_cross(self._kind[0], self._kind[1], Xs, n, Xcols, ncols_real, self.d, col0, n == self.N, nrows,
+                               ncols, out)
+
+    def _kss_diag(self):
+        """diag(K_ss) of GP_regression.py:147 without building K_ss"""
+        if self._kind is None:
+            return self.sigma ** 2
+        kind, pr = self._kind
+        if kind == 2:
+            return 1.0                                        # exp(0)
+        if kind == 3:                                         # every factor is 1 at distance 0; K_ss is square: + theta_11^2
+            return ((pr[0] * pr[0] + pr[2] * pr[2]) + pr[5] * pr[5]) + (pr[8] * pr[8] + pr[10] * pr[10])
+        Xs = self.Xs.cpu().numpy()
+        kss = np.zeros(self.n)
+        for k in range(self.d):                               # (x - c).(x - c), summed in input order
+            e = Xs[:, k] - pr[0]
+            kss = kss + e * e
+        return kss
 
     # ------------------------------------------------------------------ data
     def set_train(self, X, y):
@@ -655,9 +727,10 @@ class DistGP:
         self._vinv_blocks = set()
         self.info.fill_(INT64_MAX)
         # K + sI: my row blocks, lower part
+        if self._kind is not None and self._kind[0] == 2 and self.d != 1:
+            raise ValueError("the periodic kernel is 1-D only (GP_regression.py:48)")
         for li, b in enumerate(self.my_blocks):
-            ops.rbf_rows(self.X, self.N, self.d, b * NB, NB, (b + 1) * NB, sigma, ell, noise_var,
-                         A[li * NB:(li + 1) * NB])
+            self._cov_rows(self.X, self.N, b * NB, NB, (b + 1) * NB, noise_var, A[li * NB:(li + 1) * NB])
         if self.yrow is not None:
             A[self.yrow:self.yrow + YB, :self.Np].zero_()
             A[self.yrow, :self.N].copy_(self.y)
@@ -763,8 +836,8 @@ class DistGP:
         ops, NB, G, A, V = self.ops, self.NB, self.G, self.A, self.V
         with self._concurrent(bool(self.lookahead)):
             for li, b in enumerate(self.my_blocks):
-                ops.rbf_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, self.d, self.n_p, NB,
-                              self.sigma, self.ell, V[:, li * NB:(li + 1) * NB])
+                self._cov_cross(self.Xs, self.n, self.X[b * NB:], self.N - b * NB, b * NB, self.n_p, NB,
+                                V[:, li * NB:(li + 1) * NB])
                 self.m_loc[li * NB:(li + 1) * NB].copy_(self.m[b * NB:(b + 1) * NB])
             T = self.T
 
@@ -831,7 +904,7 @@ class DistGP:
         for r in range(G):                     # fixed order: bitwise reproducible
             mu += alld[r, 0]
             sq += alld[r, 1]
-        var = self.sigma ** 2 - sq[:self.n]
+        var = self._kss_diag() - sq[:self.n]
         self.have_v = True
         self.stage_ms["predict"] = (time.perf_counter() - t_begin) * 1e3
         with np.errstate(invalid="ignore"):
@@ -858,7 +931,7 @@ class DistGP:
             ops.gemm_nt(Gm[:, :n_p], self.V[:, :self.nloc * NB], self.V[:, :self.nloc * NB])     # Gm = -v_loc^T v_loc
         if self.coll:
             self.comm.all_reduce(Gm, "sum")
-        ops.rbf_rows(self.Xs, self.n, self.d, 0, n_p, n_p, self.sigma, self.ell, float(jitter), P)
+        self._cov_rows(self.Xs, self.n, 0, n_p, n_p, float(jitter), P)
         P[:, :n_p].add_(Gm[:, :n_p])
         info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         ops.potrf_block(P[:, :n_p], 0, info)
@@ -879,6 +952,8 @@ class DistGP:
         the alpha alpha^T term is added on rank 0 only, and the 2 x G partial traces are summed in rank order."""
         if not self.have_factor:
             raise ValueError("no factorisation resident (call factorize)")
+        if self._kind is not None:
+            raise ValueError("lml_grad: squared-exponential kernel only (tune_hyperparms_regression.py:54)")
         ops, NB, G, A, T, Np = self.ops, self.NB, self.G, self.A, self.T, self.Np
         alpha = self.alpha()                                   # full vector, every rank
         a_full = self._tensor(Np)

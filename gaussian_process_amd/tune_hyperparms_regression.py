@@ -56,9 +56,10 @@ def bayesian_opt(X_train, X_test, y_train, *, ctx=None):
 # :316-395, :418-432 (candidate sampling, the loop, the driver).  Host code: the surrogate
 # GP has at most ~5 points; the accelerated part is compute_mar_likelihood_batch.
 # Plotting (plot_BO, the plt calls inside the acquisition functions) is out of scope.
-# The reference's Python-2 `random` stream cannot be reproduced by Python 3, so the outer
-# loop has no golden vectors ("parity unpinned"); its pieces are tested against their
-# formulas and the evaluated LMLs against the oracle.
+# Pinned: the reference's own functions, print statements passed through lib2to3's fixers, were run with `random`
+# and `np.random` seeded (oracle/make_golden.py:bo_loop_cases); every candidate set, surrogate posterior, chosen
+# lengthscale and returned maximum of those runs is in tests/golden/kernels_bo_loops.npz, and the loops below
+# reproduce them point for point (tests/test_host_logic.py on the CPU, the -m gpu tests free-running).
 # ---------------------------------------------------------------------------------------
 import random  # noqa: E402
 

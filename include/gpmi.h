@@ -69,12 +69,18 @@ int gpmi_ctx_destroy(gpmi_ctx* ctx);
  * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
  *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "lanes" (factorisations in flight in
  *               gpmi_lml_batch, 0 = by size), "ramp" (bit mask, default 0: 1 block widths ramp up at the start of the
- *               sweep, 2 half width over the last blocks, 4 quarter width for the last one, when "nb" is automatic);
+ *               sweep, 2 half width over the last blocks, 4 quarter width for the last one, bits 4.. = how many blocks
+ *               count as "last" (0: three), when "nb" is automatic.  Until round 2 any non-zero value meant "up and
+ *               down": that is 3 now; other bits or a negative value are refused),
+ *               "shallow_min" (under lookahead, panels with fewer columns left than this use the one-launch panel
+ *               kernels: the update they would run beside is over long before they are; default 6144, 0 = never);
  *               kernel selection (for measurements; also per context -- the lanes of gpmi_lml_batch inherit them):
  *               "panel_fused" (0/1: 128-column MFMA panel kernels / first-generation 64-column leaves),
  *               "gemm_dma" (0/1), "gemm_dma_waves" (4/8), "gemm_small_tiles" (0/1), "gemm_small_dma" (0/1),
  *               "gemm_persist" (0/1: resident workgroups for update GEMMs that have the chip to themselves),
- *               "trsv_vinv" (0/1: backward solve through the inverted 128 x 128 diagonal blocks / 16 x 16 rounds),
+ *               "trsv_vinv" (backward solve: 2 ONE launch, column blocks chained through the solution vector, with the
+ *               inverted 128 x 128 diagonal blocks -- the default; 1 one launch per block with the same inverses; 0 the
+ *               16 x 16 rounds),
  *               "trsm_wave" (0/1), "rbf_blocks" (persistent blocks of the K build).
  * The context-free gpmi_dev_* primitives run with the defaults. */
 int gpmi_set_option(gpmi_ctx* ctx, const char* name, int64_t value);
@@ -183,8 +189,8 @@ int gpmi_sync(gpmi_ctx* ctx);
 /* fp64 MFMA issue rate: returns achieved TFLOP/s of a register-only
  * v_mfma_f64_16x16x4_f64 loop over the whole chip. */
 int gpmi_probe_mfma_f64(gpmi_ctx* ctx, double* tflops);
-/* same loop with blocks_per_cu workgroups of 4 waves per CU and nacc (4, 8, 16)
- * independent accumulators per wave; out[0] = TFLOP/s, out[1] = shader clock in
+/* same loop with one workgroup of 4 * blocks_per_cu waves on every CU (blocks_per_cu = waves per SIMD, 1 .. 4) and nacc
+ * (4, 8, 16) independent accumulators per wave; out[0] = TFLOP/s, out[1] = shader clock in
  * GHz held during the loop, out[2] = shader cycles per MFMA per SIMD */
 int gpmi_probe_mfma_f64_ex(gpmi_ctx* ctx, int blocks_per_cu, int nacc, int iters, double* out);
 /* one launch shape of the trailing-update GEMM on scratch buffers; variant = timing-only
@@ -219,6 +225,17 @@ int gpmi_dev_rbf_rows(void* stream, const double* X_dev, int64_t N, int64_t d,
 int gpmi_dev_rbf_cross(void* stream, const double* Xs_dev, int64_t n, const double* X_dev,
                        int64_t N, int64_t d, int64_t row0, int64_t nrows, int64_t ncols,
                        double sigma, double ell, double* out_dev, int64_t ld);
+/* The same two builds for every covariance function the reference's prediction() serves (GP_regression.py:125-136:
+ * 'rbf' / 'lin' / 'per') and for CO2_example.py:66-90's composite -- f4 on the row-block partitioned path.
+ * kind / params as gpmi_set_kernel (0: sigma, l; 1: c; 2: period, l -- 1-D inputs) and gpmi_set_kernel_params (3: the
+ * 11 hyper-parameters; kernel_4 adds theta_11^2 on the diagonal of a square matrix).  gpmi_dev_cov_cross takes a WINDOW
+ * of the column inputs that starts at input col0 of the full set; square != 0: the full cross matrix is square (n == N),
+ * so the composite kernel's delta term lands on row == col0 + column (CO2_example.py:58-62). */
+int gpmi_dev_cov_rows(void* stream, int kind, const double* params, int nparams, const double* X_dev, int64_t N, int64_t d,
+                      int64_t row0, int64_t nrows, int64_t ncols, double noise_var, double* out_dev, int64_t ld);
+int gpmi_dev_cov_cross(void* stream, int kind, const double* params, int nparams, const double* Xs_dev, int64_t n,
+                       const double* Xcols_dev, int64_t ncols_real, int64_t d, int64_t col0, int square, int64_t nrows,
+                       int64_t ncols, double* out_dev, int64_t ld);
 /* in-place Cholesky of the nb x nb diagonal block (nb multiple of 128);
  * info_dev: int64 on the device, atomically min-ed with col_offset + failing
  * column (initialise to INT64_MAX).  On return the lower triangle holds L; the strict upper triangles of

@@ -48,6 +48,58 @@ class NumpyBlockOps:
             blk[:n, :cc] = O.RBF_kernel(self._a(Xs)[:n], self._a(Xcols)[:cc], sigma, ell)
         o[:nrows, :ncols] = blk
 
+    @staticmethod
+    def _cov(kind, params, a, b, square_delta_col0=None):
+        """the oracle's covariance functions; kind 3's delta term (CO2_example.py:58-62) on row == col + col0 when asked"""
+        if kind == 0:
+            return O.RBF_kernel(a, b, params[0], params[1])
+        if kind == 1:
+            return O.lin_kernel(a, b, params[0])
+        if kind == 2:
+            return O.per_kernel(a, b, (params[0], params[1]))
+        sq = ((a[:, None, :] - b[None, :, :]) ** 2).sum(axis=2) if a.shape[1] > 1 else ((a[:, :, None] - b[:, :, None].T) ** 2).sum(1)
+        t = params
+        r = np.sqrt(sq)
+        k1 = (t[0] ** 2) * np.exp(-.5 * sq / t[1] ** 2)
+        k2 = t[2] ** 2 * np.exp(-.5 * sq / t[3] ** 2 + (-2 * ((np.sin(np.pi * r)) / t[4]) ** 2))
+        k3 = t[5] ** 2 * (1.0 / np.power(1 + .5 * sq / (t[7] * t[6] ** 2), t[7]))
+        delta = np.zeros_like(sq)
+        if square_delta_col0 is not None:
+            for i in range(sq.shape[0]):
+                j = i - square_delta_col0
+                if 0 <= j < sq.shape[1]:
+                    delta[i, j] = 1.0
+        k4 = t[8] ** 2 * np.exp(-.5 * sq / t[9] ** 2) + t[10] ** 2 * delta
+        return k1 + k2 + k3 + k4
+
+    def cov_rows(self, kind, params, X, N, d, row0, nrows, ncols, noise_var, out):
+        Xn = self._a(X)
+        o = self._a(out)
+        rows = np.arange(row0, row0 + nrows)
+        blk = np.zeros((nrows, ncols))
+        rr = rows[rows < N]
+        cc = min(N, ncols)
+        if len(rr) and cc > 0:
+            # the symmetric build is square: kernel_4's delta sits on global row == global column
+            blk[:len(rr), :cc] = self._cov(kind, params, Xn[rr], Xn[:cc], square_delta_col0=-int(row0) if kind == 3 else None)
+        for i, r in enumerate(rows):
+            if r < ncols:
+                blk[i, r] = blk[i, r] + noise_var if r < N else 1.0
+        for i in range(0, nrows, 128):
+            first_dead = (row0 + i) // 128 * 128 + 128
+            if first_dead < ncols:
+                blk[i:i + 128, first_dead:] = np.nan
+        o[:nrows, :ncols] = blk
+
+    def cov_cross(self, kind, params, Xs, n, Xcols, ncols_real, d, col0, square, nrows, ncols, out):
+        o = self._a(out)
+        blk = np.zeros((nrows, ncols))
+        cc = max(min(ncols_real, ncols), 0)
+        if cc > 0:
+            blk[:n, :cc] = self._cov(kind, params, self._a(Xs)[:n], self._a(Xcols)[:cc],
+                                     square_delta_col0=int(col0) if (kind == 3 and square) else None)
+        o[:nrows, :ncols] = blk
+
     def potrf_block(self, A, col_offset, info):
         a = self._a(A)
         low = np.tril(a)

@@ -200,6 +200,63 @@ def test_eight_ranks_on_one_gpu_hip(oracle, world, N, d, n, nb, la):
     _thread_ranks(world, "cuda", N, d, n, nb, la, oracle, grad=N <= 4096)
 
 
+def _run_kernels(world, device, tmp_path, nb, lookahead=2):
+    port = _free_port()
+    out = str(tmp_path / "kres")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", DISTGP_LOOKAHEAD=str(lookahead))
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker_kernels.py"), str(r), str(world),
+                               port, "gloo", device, out, str(nb)], env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=600) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return [np.load(out + "_rank%d.npz" % r) for r in range(world)]
+
+
+def _check_kernels(res, oracle):
+    """f4 on the partitioned path against the reference's own outputs (kernels_lin_per.npz: prediction(..., 'lin' / 'per')
+    of GP_regression.py:125-136; kernels_bo_co2.npz: CO2_example.py's compute_mar_likelihood / make_prediction executed
+    from source), the oracle for the square-K_s case, and equal bits on every rank"""
+    from conftest import golden
+    g, z = golden("kernels_lin_per"), golden("kernels_bo_co2")
+    r = res[0]
+    assert np.allclose(r["lin_mu"], g["lin_mu"], atol=1e-9) and np.allclose(r["lin_sd"], g["lin_sd"], atol=1e-9)
+    assert np.allclose(r["lin_fp"], g["lin_fpost"], atol=1e-6)
+    assert np.allclose(r["per_mu"], g["per_mu"], atol=1e-9) and np.allclose(r["per_sd"], g["per_sd"], atol=1e-9)
+    assert np.allclose(r["per_fp"], g["per_fpost"], atol=1e-6)
+    want = oracle.compute_mar_likelihood(g["X"], None, g["y_lin"], 1.0, 1.3)
+    assert abs(r["rbf_lml"] - want) <= 1e-10 * abs(want)
+    assert abs(r["co2_lml"] - float(z["co2_lml"])) <= 1e-9 * abs(float(z["co2_lml"]))
+    scale = np.abs(z["co2_mu"]).max()
+    assert np.allclose(r["co2_mu"], z["co2_mu"], rtol=0, atol=1e-8 * scale)
+    assert np.allclose(r["co2_sd"], z["co2_sd"], rtol=0, atol=1e-8, equal_nan=True)
+    assert np.allclose(r["co2_fp"], z["co2_fpost"], rtol=0, atol=1e-5 * scale)
+    mu, sd, _, _ = oracle.co2_posterior(z["co2_X"], z["co2_X"] + 0.37, z["co2_y"], z["co2_theta"], 5e-4)
+    assert np.allclose(r["co2_sq_mu"], mu, rtol=0, atol=1e-8 * scale)
+    assert np.allclose(np.sqrt(np.maximum(r["co2_sq_var"], 0)), np.nan_to_num(sd), rtol=0, atol=1e-7)
+    assert int(r["grad_refused"]) == 1
+    for q in res[1:]:
+        for key in r.files:
+            assert np.array_equal(q[key], r[key], equal_nan=True), key
+
+
+@pytest.mark.parametrize("world,nb", [(2, 128), (3, 128), (2, 256)])
+def test_other_covariance_functions_on_the_partition_gloo_cpu(oracle, tmp_path, world, nb):
+    """prediction(..., 'lin' / 'per', dist=gp) and the CO2 composite kernel through DistGP (SURVEY.md section 8f row f4 on
+    the partitioned path), NumPy stand-ins for the block primitives"""
+    _check_kernels(_run_kernels(world, "cpu", tmp_path, nb), oracle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,nb,la", [(2, 128, 2), (3, 128, 1), (1, 256, 2)])
+def test_other_covariance_functions_on_the_partition_hip(oracle, tmp_path, world, nb, la):
+    """the same with the HIP primitives (gpmi_dev_cov_rows / gpmi_dev_cov_cross), ranks sharing the test box's GPU"""
+    _check_kernels(_run_kernels(world, "cuda", tmp_path, nb, lookahead=la), oracle)
+
+
 def test_two_ranks_gloo_cpu_without_lookahead(oracle, tmp_path):
     res = _run(2, "gloo", "cpu", tmp_path, 640, 4, 40, 128, lookahead=0)
     _check(res, oracle, 640, 4, 40)

@@ -901,6 +901,34 @@ def test_backward_solve_with_inverted_diagonal_blocks(ctx, oracle, N):
     assert np.allclose(g0, g1, rtol=1e-12, atol=0)
 
 
+@pytest.mark.parametrize("ell,s2", [(4.0, 1e-6), (6.0, 1e-5)])
+def test_backward_solve_inverted_blocks_at_low_noise(ctx, oracle, ell, s2):
+    """a5 where the explicit 128 x 128 inverses are least comfortable: a smooth kernel with little noise (cond(K + sI) ~
+    1e9-1e10, max|alpha| ~ 1e5).  A product with L_kk^-1 is accurate to cond(L_kk) eps, substitution to eps: the two must
+    still agree far inside what alpha itself carries (cond(K) eps), and both must sit at the oracle's distance."""
+    N = 3000
+    X, y, Xs = oracle.synthetic_problem(N, 8, 16, seed=11)
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, ell, s2)
+    ctx.fit(X, y, 1.0, ell, s2)
+    try:
+        ctx.set_option("trsv_vinv", 0)
+        a_rounds = ctx.alpha()
+    finally:
+        ctx.set_option("trsv_vinv", 2)
+    a = ctx.alpha()
+    d_forms, d_oracle, d_rounds_oracle = relmax(a, a_rounds), relmax(a, ref["alpha"]), relmax(a_rounds, ref["alpha"])
+    print("low noise ell=%g s=%g: max|alpha| %.3g, inverted vs rounds %.2e, inverted vs oracle %.2e, rounds vs oracle %.2e"
+          % (ell, s2, np.abs(a).max(), d_forms, d_oracle, d_rounds_oracle))
+    assert d_forms <= 1e-9
+    assert d_oracle <= max(1e-8, 3 * d_rounds_oracle)
+    # and the residual of the system itself, on sampled rows
+    coef = -.5 * (1 / (ell ** 2))
+    for i in np.random.default_rng(2).choice(N, 8, replace=False):
+        ki = np.exp(coef * ((X - X[i]) ** 2).sum(1))
+        ki[i] += s2
+        assert abs(ki @ a - y[i]) <= 1e-9 * max(1.0, np.abs(a).max() * 1e-3)
+
+
 def test_backward_solve_one_launch_many_blocks_repeatable(ctx, oracle):
     """a5 at a size where the chain is 256 workgroups long (N = 32768: two per CU on half the chip) and every column
     block has waited on its predecessor: ten solves on one factor give the same bits (the summation order does not
