@@ -385,6 +385,54 @@ def fit_predict_feasible(X_train, X_test, y_train, sigma, l, s, rows=256, use_c=
     return dict(mu=mu, var=var, alpha=alpha, m=m, lml=lml, diagL=np.diagonal(L).copy())
 
 
+def fit_predict_blocked(X_train, X_test, y_train, sigma, l, s, block=4096, timings=None, progress=None):
+    """fit_predict_feasible for sizes where LAPACK's dpotrf on the host would take too long (N = 131072: 7.5e14 flop):
+    the same statements (GP_regression.py:138-148, tune_hyperparms_regression.py:312), the Cholesky factorisation
+    written out as the blocked right-looking algorithm LAPACK itself uses -- dpotrf on a diagonal block, dtrsm on the
+    rows below, dsyrk / dgemm on the trailing lower block columns -- with a block of 4096 instead of LAPACK's 64-256, so
+    that nearly all flops are large dgemm calls.  Same arithmetic per element up to the order of the K-long sums; checked
+    against fit_predict_feasible in tests/test_oracle_vs_golden.py.  In place on the lower triangle of K."""
+    import time
+    import scipy.linalg as sla
+    N = len(X_train)
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + (t[-1] - t[-2])
+    A = RBF_kernel_c(X_train, X_train, sigma, l)
+    A[np.diag_indices(N)] += s                                                   # :138
+    lap("kbuild")
+    for k in range(0, N, block):
+        e = min(k + block, N)
+        Lkk = sla.cholesky(A[k:e, k:e], lower=True, check_finite=False)          # dpotrf
+        A[k:e, k:e] = Lkk
+        if e < N:
+            P = sla.solve_triangular(Lkk, A[e:, k:e].T, lower=True, check_finite=False).T   # dtrsm: rows below
+            A[e:, k:e] = P
+            for j in range(e, N, block):                                         # trailing update, lower block columns only
+                je = min(j + block, N)
+                A[j:, j:je] -= P[j - e:] @ P[j - e:je - e].T
+        if progress is not None:
+            progress(e, N)
+    lap("chol")
+    diagL = np.diagonal(A).copy()
+    # triangular solves against the lower triangle (the strict upper triangle still holds K: masked by `lower=True`)
+    m = sla.solve_triangular(A, y_train, lower=True, check_finite=False)         # :139
+    alpha = sla.solve_triangular(A, m, lower=True, trans='T', check_finite=False)    # :140
+    lap("trsv")
+    K_s = RBF_kernel_c(X_train, X_test, sigma, l)
+    mu = K_s.T @ alpha                                                           # :143
+    lap("ks")
+    v = sla.solve_triangular(A, K_s, lower=True, overwrite_b=True, check_finite=False)   # :144
+    lap("trsm")
+    var = sigma ** 2 - np.einsum('ij,ij->j', v, v)                               # :147
+    lml = (-.5 * float(y_train @ alpha) - float(np.log(diagL).sum()) - N / 2.0 * np.log(2 * np.pi))   # tune...:312
+    lap("meanvar")
+    return dict(mu=mu, var=var, alpha=alpha, m=m, lml=lml, diagL=diagL)
+
+
 def synthetic_problem(N, d, n, seed=20240531):
     """SURVEY.md section 8(d) synthetic inputs (the bench / parity workload)."""
     rng = np.random.default_rng(seed)

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--ell", type=float, default=2.0)
     ap.add_argument("--stride", type=int, default=8)
     ap.add_argument("--gpu", action="store_true")
+    ap.add_argument("--max-seconds", type=float, default=900.0, help="give up early if the factorisation is projected to take longer")
+    ap.add_argument("--blocked", type=int, default=0, help="block width of oracle.fit_predict_blocked (0: LAPACK dpotrf on the whole matrix)")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import gp_oracle as O
@@ -56,7 +58,16 @@ def main():
         while not done.wait(60.0):
             print("  ... oracle running, %.0f s, stages so far %s" % (time.perf_counter() - t0, list(tm.keys())), flush=True)
     threading.Thread(target=heartbeat, daemon=True).start()
-    ref = O.fit_predict_feasible(X, Xs, y, 1.0, a.ell, 5e-4, timings=tm)
+    if a.blocked:
+        def progress(e, n):
+            el = time.perf_counter() - t0
+            frac = 1.0 - (1.0 - e / float(n)) ** 3                 # share of the N^3/3 flops behind us
+            print("  ... factored %d of %d columns, %.0f s, projected %.0f s" % (e, n, el, el / max(frac, 1e-9)), flush=True)
+            if e >= 2 * a.blocked and el / frac > a.max_seconds:
+                raise SystemExit("projected factorisation time %.0f s exceeds --max-seconds %.0f" % (el / frac, a.max_seconds))
+        ref = O.fit_predict_blocked(X, Xs, y, 1.0, a.ell, 5e-4, block=a.blocked, timings=tm, progress=progress)
+    else:
+        ref = O.fit_predict_feasible(X, Xs, y, 1.0, a.ell, 5e-4, timings=tm)
     wall = time.perf_counter() - t0
     done.set()
     print("oracle N=%d: %.1f s  stages %s" % (a.N, wall, {k: round(v, 1) for k, v in tm.items()}), flush=True)
@@ -66,8 +77,9 @@ def main():
              m_s=ref["m"][::st], alpha_absmax=np.abs(ref["alpha"]).max(),
              oracle_seconds=wall, oracle_stage_names=np.array(list(tm.keys())), oracle_stage_seconds=np.array(list(tm.values())),
              host_cores=os.cpu_count(),
-             provenance="ORACLE-GENERATED (oracle/gp_oracle.py:fit_predict_feasible on the GPU box's host cores via "
-                        "scripts/oracle_fullsize.py); not an output of the reference, which cannot run this size")
+             provenance="ORACLE-GENERATED (oracle/gp_oracle.py:%s on the GPU box's host cores via "
+                        "scripts/oracle_fullsize.py); not an output of the reference, which cannot run this size"
+                        % ("fit_predict_blocked, block %d" % a.blocked if a.blocked else "fit_predict_feasible"))
     print("wrote", out, os.path.getsize(out), "bytes", flush=True)
     if not a.gpu:
         return

@@ -179,3 +179,17 @@ def test_co2_composite_kernel_and_paths(oracle):
     mu, sd = oracle.co2_bayesian_opt(g["co2_hp"], g["co2_hq"], g["co2_hp_lml"])
     assert np.array_equal(mu, g["co2_bo_mu"]) and np.array_equal(sd, g["co2_bo_sd"], equal_nan=True)
     assert np.array_equal(oracle.co2_covariance_function(g["co2_hp"], g["co2_hq"], g["co2_hp"][0]), g["co2_Khp"])
+
+
+def test_blocked_oracle_equals_the_lapack_one():
+    """oracle.fit_predict_blocked (the factorisation written out in 4096-wide blocks, used once for the N = 131072 fixture
+    of BASELINE config 4) against oracle.fit_predict_feasible (LAPACK dpotrf on the whole matrix): two orders of the same
+    sums, so they agree to cond x eps; ragged last block"""
+    import gp_oracle as O
+    X, y, Xs = O.synthetic_problem(1500, 16, 40, seed=5)
+    a = O.fit_predict_feasible(X, Xs, y, 1.0, 2.8, 5e-4)
+    b = O.fit_predict_blocked(X, Xs, y, 1.0, 2.8, 5e-4, block=384)
+    assert np.max(np.abs(a["mu"] - b["mu"])) <= 1e-10 and np.max(np.abs(a["var"] - b["var"])) <= 1e-11
+    assert abs(a["lml"] - b["lml"]) <= 1e-11 * abs(a["lml"])
+    assert np.max(np.abs(a["alpha"] - b["alpha"])) <= 1e-9 * np.max(np.abs(a["alpha"]))
+    assert np.max(np.abs(a["diagL"] - b["diagL"]) / a["diagL"]) <= 1e-12
