@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void gemv_t_partial2_kernel(const double* __re
             d2 v[64];
 #pragma unroll
             for (int r = 0; r < 64; ++r) v[r] = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+            __builtin_amdgcn_sched_barrier(0);      // all 64 requests first (left alone the compiler keeps ~10 in flight: 58 registers, 3 TB/s)
 #pragma unroll
             for (int r = 0; r < 64; ++r) {
                 a0 = fma(v[r].x, xs[64 * half + r], a0);
