@@ -563,38 +563,45 @@ __global__ void gemv_t_sum_kernel(const double* part, int64_t nchunks, int64_t n
     y[c] = s;
 }
 
-// the same partial sums for even ncols / ld: a workgroup takes 128 rows x 256 columns, a thread one column pair and
-// 64 of the rows with all of its 16-byte loads in flight at once (the access pattern of the backward solve's update:
-// 2-KiB row segments), the two halves summed in a fixed order
+// the same partial sums for even ncols / ld: a workgroup takes rpw x 128 rows x 256 columns, 128 rows at a time: a thread
+// one column pair and 64 of the rows with all of its 16-byte loads in flight at once (the access pattern of the backward
+// solve's update: 2-KiB row segments), the two halves summed in a fixed order.  rpw keeps the number of partial sums per
+// column small: the kernel that adds them up has one thread per column and walks them one after the other (with one
+// partial per 128 rows that walk -- 480 dependent-ish loads at N = 65536 -- took as long as the streaming pass).
 __global__ __launch_bounds__(256) void gemv_t_partial2_kernel(const double* __restrict__ A, int64_t ld, int64_t nrows,
-                                                               int64_t ncols, const double* __restrict__ x, double* part) {
+                                                               int64_t ncols, const double* __restrict__ x, double* part,
+                                                               int rpw) {
     __shared__ double xs[128];
     __shared__ double hs[256];
     const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.y * 128;
-    if (tid < 128) xs[tid] = (r0 + tid < nrows) ? x[r0 + tid] : 0.0;
-    __syncthreads();
     const int half = tid >> 7;
     const int64_t c = (int64_t)blockIdx.x * 256 + 2 * (tid & 127);
     double a0 = 0., a1 = 0.;
-    if (c < ncols) {
-        const int64_t rb = r0 + 64 * half;
-        const double* col = A + rb * ld + c;
-        if (rb + 64 <= nrows) {
-            d2 v[64];
+    for (int q = 0; q < rpw; ++q) {
+        const int64_t r0 = ((int64_t)blockIdx.y * rpw + q) * 128;
+        if (r0 >= nrows) break;
+        __syncthreads();
+        if (tid < 128) xs[tid] = (r0 + tid < nrows) ? x[r0 + tid] : 0.0;
+        __syncthreads();
+        if (c < ncols) {
+            const int64_t rb = r0 + 64 * half;
+            const double* col = A + rb * ld + c;
+            if (rb + 64 <= nrows) {
+                d2 v[64];
 #pragma unroll
-            for (int r = 0; r < 64; ++r) v[r] = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
-            __builtin_amdgcn_sched_barrier(0);      // all 64 requests first (left alone the compiler keeps ~10 in flight: 58 registers, 3 TB/s)
+                for (int r = 0; r < 64; ++r) v[r] = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+                __builtin_amdgcn_sched_barrier(0);      // all 64 requests first (left alone the compiler keeps ~10 in flight)
 #pragma unroll
-            for (int r = 0; r < 64; ++r) {
-                a0 = fma(v[r].x, xs[64 * half + r], a0);
-                a1 = fma(v[r].y, xs[64 * half + r], a1);
-            }
-        } else {
-            for (int r = 0; rb + r < nrows && r < 64; ++r) {
-                const d2 v = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
-                a0 = fma(v.x, xs[64 * half + r], a0);
-                a1 = fma(v.y, xs[64 * half + r], a1);
+                for (int r = 0; r < 64; ++r) {
+                    a0 = fma(v[r].x, xs[64 * half + r], a0);
+                    a1 = fma(v[r].y, xs[64 * half + r], a1);
+                }
+            } else {
+                for (int r = 0; rb + r < nrows && r < 64; ++r) {
+                    const d2 v = *reinterpret_cast<const d2*>(col + (int64_t)r * ld);
+                    a0 = fma(v.x, xs[64 * half + r], a0);
+                    a1 = fma(v.y, xs[64 * half + r], a1);
+                }
             }
         }
     }
@@ -610,9 +617,12 @@ hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nro
                          const double* x, double* y, double* scratch) {
     if (ncols <= 0) return hipSuccess;
     if (nrows > 0 && ncols % 2 == 0 && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0) {
-        const int64_t nch = (nrows + 127) / 128;
-        hipLaunchKernelGGL(gemv_t_partial2_kernel, dim3((unsigned)((ncols + 255) / 256), (unsigned)nch), dim3(256), 0, s,
-                           A, ld, nrows, ncols, x, scratch);
+        const int64_t nch128 = (nrows + 127) / 128, ccols = (ncols + 255) / 256;
+        // row chunks per workgroup: as many as still leave ~1024 workgroups in the launch, at most 16
+        int rpw = (int)std::min<int64_t>(16, std::max<int64_t>(1, nch128 * ccols / 1024));
+        const int64_t nch = (nch128 + rpw - 1) / rpw;
+        hipLaunchKernelGGL(gemv_t_partial2_kernel, dim3((unsigned)ccols, (unsigned)nch), dim3(256), 0, s,
+                           A, ld, nrows, ncols, x, scratch, rpw);
         hipLaunchKernelGGL(gemv_t_sum_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, scratch, nch, ncols, y);
         return hipGetLastError();
     }
