@@ -214,6 +214,12 @@ def main():
                           "port": os.environ.get("MASTER_PORT")}), flush=True)
         sys.exit(3 if echo == "fail" + os.environ.get("RANK", "0") else 0)
 
+    # stdout carries exactly ONE line, the result: whatever libraries print meanwhile (RCCL's version banner under
+    # NCCL_DEBUG=VERSION goes to stdout at communicator creation) is sent to stderr by pointing fd 1 there until the end
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -477,7 +483,10 @@ def main():
         out["targets"] = targets
         if world == 1 and not args.no_cpu_baseline and not force_dist:
             out["cpu_baseline"] = cpu_baseline(d, n)
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if multi:
         dist.destroy_process_group()
 
