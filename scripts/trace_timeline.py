@@ -46,3 +46,15 @@ if nlist:
     for name, s, e, q, gx, wx, lds in sel:
         short = name.replace("gpmi::", "").replace("void ", "")[:46]
         print("q%-2s %9.1f -> %9.1f  (%7.1f)  grid %6d x %3d lds %6d  %s" % (q, (s - tz) / 1e3, (e - tz) / 1e3, (e - s) / 1e3, gx // max(wx, 1), wx, lds, short))
+
+# raw listing of the predict phase: everything after the LAST lml_reduce_kernel (TRACE_PREDICT=k kernels)
+npred = int(os.environ.get("TRACE_PREDICT", "0"))
+if npred:
+    allrows = c.execute("select name, start, end, %s, grid_x, workgroup_x, lds_size from kernels order by start" % (qcol or "0")).fetchall()
+    idx = max(i for i, r in enumerate(allrows) if "lml_reduce" in r[0])
+    sel = allrows[idx:idx + npred]
+    tz = sel[0][1]
+    print("---- %d kernels from the end of the last factorisation on (predict phase; us)" % len(sel))
+    for name, s_, e_, q, gx, wx, lds in sel:
+        short = name.replace("gpmi::", "").replace("void ", "")[:46]
+        print("q%-2s %9.1f -> %9.1f  (%7.1f)  grid %6d x %3d lds %6d  %s" % (q, (s_ - tz) / 1e3, (e_ - tz) / 1e3, (e_ - s_) / 1e3, gx // max(wx, 1), wx, lds, short))
