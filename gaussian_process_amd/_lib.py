@@ -59,6 +59,7 @@ SIGNATURES = {
     "gpmi_probe_mfma_f64": [_vp, _dp],
     "gpmi_probe_mfma_f64_ex": [_vp, C.c_int, C.c_int, C.c_int, _dp],
     "gpmi_probe_gemm": [_vp, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, _dp],
+    "gpmi_probe_resident": [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int],
     "gpmi_probe_hbm_write": [_vp, _i64, _dp],
     "gpmi_probe_hbm_ex": [_vp, _i64, C.c_int, C.c_int, _dp],
     "gpmi_device_info": [_vp, _dp, C.c_int],

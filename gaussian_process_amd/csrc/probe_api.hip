@@ -226,6 +226,63 @@ int gpmi_probe_panel(gpmi_ctx* c, int kind, int64_t m, int reps, double* out_us,
     return GPMI_OK;
 }
 
+// One resident workgroup that does nothing: `threads` threads and `lds_bytes` of LDS it never touches, asleep for
+// `milliseconds` on a stream of its own (high_priority != 0: the device's highest stream priority).  Returns at once; time
+// something else (gpmi_probe_gemm) while it is resident to see what a workgroup that merely HOLDS a CU costs the rest of the
+// chip (the resident potrf128 chain).
+__global__ void probe_sleeper_kernel(unsigned long long ticks, const unsigned long long* poll, int poll_sleep, int fences) {
+    const unsigned long long t0 = wall_clock64();
+    if (!poll) {
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+        return;
+    }
+    // the way a flag-chained resident kernel waits: thread 0 re-reads a device flag with agent-scope atomic loads
+    // (poll_sleep = argument of s_sleep between two reads); fences != 0: an agent-scope acquire + release pair every
+    // ~30 us, as a kernel would issue around each unit of work it is released for
+    if (threadIdx.x == 0) {
+        unsigned long long acc = 0, last = t0;
+        while (wall_clock64() - t0 < ticks) {
+            acc += __hip_atomic_load(poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (poll_sleep == 1) __builtin_amdgcn_s_sleep(1);
+            else if (poll_sleep <= 2) __builtin_amdgcn_s_sleep(2);
+            else if (poll_sleep <= 16) __builtin_amdgcn_s_sleep(16);
+            else __builtin_amdgcn_s_sleep(64);
+            if (fences && wall_clock64() - last > 3000) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                last = wall_clock64();
+            }
+        }
+        if (acc == 0x123456789ull) __builtin_trap();
+    }
+}
+
+int gpmi_probe_resident(gpmi_ctx* c, int high_priority, int lds_bytes, int threads, double milliseconds, int poll_sleep,
+                        int fences) {
+    if (!c || lds_bytes < 0 || lds_bytes > 160 * 1024 || threads < 64 || threads > 1024 || threads % 64 ||
+        !(milliseconds > 0.0) || milliseconds > 5000.0)
+        return fail_arg("gpmi_probe_resident: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high_priority ? hi : lo));
+    hipError_t e = hipFuncSetAttribute((const void*)probe_sleeper_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) {
+        const unsigned long long* flag = nullptr;
+        if (poll_sleep > 0) {
+            if (c->red.ensure(16 * 8) != hipSuccess) { (void)hipStreamDestroy(st); return fail_arg("gpmi_probe_resident: no scratch"); }
+            flag = reinterpret_cast<const unsigned long long*>(c->red.as<double>() + 12);
+        }
+        hipLaunchKernelGGL(probe_sleeper_kernel, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st,
+                           (unsigned long long)(milliseconds * 1e5), flag, poll_sleep, fences);      // wall_clock64: 100 MHz
+        e = hipGetLastError();
+    }
+    (void)hipStreamDestroy(st);          // released when the kernel has finished
+    if (e != hipSuccess) return fail_runtime(e, "probe_sleeper launch");
+    return GPMI_OK;
+}
+
 int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
     return gpmi_probe_hbm_ex(c, bytes, 0, 2048, gbps);
 }

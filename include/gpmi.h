@@ -197,6 +197,12 @@ int gpmi_probe_mfma_f64_ex(gpmi_ctx* ctx, int blocks_per_cu, int nacc, int iters
  * ablation bits (0 = the production kernel); out[0] = TFLOP/s, out[1] = ms per launch */
 int gpmi_probe_gemm(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps,
                     double* out);
+/* one resident workgroup that does nothing (threads, lds_bytes of untouched LDS), asleep for `milliseconds` on a stream of its
+ * own (high_priority != 0: highest stream priority); returns at once -- time gpmi_probe_gemm while it is resident.
+ * poll_sleep > 0: instead of sleeping, thread 0 re-reads a device flag with agent-scope atomic loads, s_sleep(poll_sleep)
+ * between two reads (how a flag-chained resident kernel waits); fences != 0: plus an agent-scope acquire + release every ~30 us */
+int gpmi_probe_resident(gpmi_ctx* ctx, int high_priority, int lds_bytes, int threads, double milliseconds, int poll_sleep,
+                        int fences);
 /* streaming-store bandwidth (GB/s) over `bytes` of device memory */
 int gpmi_probe_hbm_write(gpmi_ctx* ctx, int64_t bytes, double* gbps);
 /* streaming bandwidth with a chosen access form: mode 0 grid-stride 16-byte stores, 1 the same
