@@ -33,11 +33,13 @@ def main():
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     lml = np.full(len(triples), np.nan)
+    first = int(os.environ.get("ORACLE_CFG5_FIRST", "0"))       # a call is limited to 20 minutes: the 64 triples take two
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(WORKERS) as pool:
-        for t, v, dt in pool.imap_unordered(one, [(t, l, sf, s2, N) for t, (l, sf, s2) in enumerate(triples)]):
+        for t, v, dt in pool.imap_unordered(one, [(t, l, sf, s2, N) for t, (l, sf, s2) in enumerate(triples) if t >= first]):
             lml[t] = v
             print("triple %2d (l=%g sf=%g s2=%g): lml %.9f  (%.1f s; %.0f s so far)" % (t, *triples[t], v, dt, time.perf_counter() - t0), flush=True)
+            np.save(os.path.join(out_dir, "oracle_cfg5_N%d_partial.npy" % N), lml)        # survives a kill at the limit
     np.savez(os.path.join(out_dir, "oracle_cfg5_N%d.npz" % N), N=N, d=8, seed=20240531, triples=triples, lml=lml,
              oracle_seconds=time.perf_counter() - t0, host_cores=os.cpu_count(), workers=WORKERS,
              provenance="ORACLE-GENERATED (oracle/gp_oracle.py:fit_predict_feasible per triple on the GPU box's host cores via "
