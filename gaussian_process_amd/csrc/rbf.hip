@@ -144,7 +144,12 @@ __device__ __forceinline__ double exp_neg_tab(double x, const double* __restrict
     q = fma(q, r, 1.0);
     q = q * r;                                                        // r + r^2/2 + r^3/6
     const double e = fma(T, q, T);
-    return __hiloint2double((int)(((unsigned)(m & ~(EXP_TAB - 1)) << (20 - EXP_TAB_LOG)) + (unsigned)__double2hiint(e)), __double2loint(e));
+    // 2^k into the exponent field: ((m & ~4095) << 8) + hi(e) as v_and + v_lshl_add_u32 -- left to itself the compiler
+    // canonicalises to shift, mask, add (three instructions; the K build is bound by its instruction count)
+    static_assert(20 - EXP_TAB_LOG == 8, "shift below is written out");
+    unsigned hi;
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(hi) : "v"((unsigned)m & ~(unsigned)(EXP_TAB - 1)), "v"((unsigned)__double2hiint(e)));
+    return __hiloint2double((int)hi, __double2loint(e));
 }
 
 __device__ __forceinline__ void exp_pair_tab(double x0, double x1, double& e0, double& e1, const double* tab) {
