@@ -83,6 +83,8 @@ SIGNATURES = {
     "gpmi_dev_set_concurrent": [C.c_int],
     "gpmi_dev_grad_trace": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp],
     "gpmi_dev_row_dots": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "gpmi_dev_sum_fixed": [_vp, _vp, _i64, _i64, _i64, _vp, C.c_double, _vp],
+    "gpmi_dev_axpy2d": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, C.c_double],
 }
 
 _lib = None

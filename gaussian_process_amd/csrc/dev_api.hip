@@ -276,6 +276,29 @@ int gpmi_dev_grad_trace(void* stream, const double* X_dev, int64_t N, int64_t d,
     return GPMI_OK;
 }
 
+// Fixed-order sum of `count` contributions (stride doubles apart) onto an optional base vector:
+//   out[i] = (base ? base[i] : 0) + scale * (in[i] + in[stride + i] + ... ), i < n, added in index order.
+// The partitioned path's reductions over gathered per-rank partials (the backward solve's right-hand side
+// m_k - sum_r part_r, GP_regression.py:140; the log-determinant pieces of tune_hyperparms_regression.py:312):
+// same bits on every rank, no dependence on a library's reduction tree.  out may alias base.
+int gpmi_dev_sum_fixed(void* stream, const double* in_dev, int64_t count, int64_t stride, int64_t n,
+                       const double* base_dev, double scale, double* out_dev) {
+    if (!out_dev || (count > 0 && !in_dev)) return fail_arg("gpmi_dev_sum_fixed: null pointer");
+    if (count < 0 || n < 0 || stride < 0) return fail_arg("gpmi_dev_sum_fixed: negative size");
+    HIP_TRY(launch_sum_fixed((hipStream_t)stream, in_dev, count, stride, n, base_dev, scale, out_dev));
+    return GPMI_OK;
+}
+
+// Y (rows x cols, ldy) += a * X (rows x cols, ldx) -- the assembly K_ss + jitter * I - v^T v of the posterior
+// covariance on the partitioned path (GP_regression.py:154: the all-reduced -v^T v added onto the covariance rows)
+int gpmi_dev_axpy2d(void* stream, double* Y_dev, int64_t ldy, const double* X_dev, int64_t ldx, int64_t rows,
+                    int64_t cols, double a) {
+    if (!Y_dev || !X_dev) return fail_arg("gpmi_dev_axpy2d: null pointer");
+    if (rows < 0 || cols < 0 || ldy < cols || ldx < cols) return fail_arg("gpmi_dev_axpy2d: bad dimensions");
+    HIP_TRY(launch_axpy2d((hipStream_t)stream, Y_dev, ldy, X_dev, ldx, rows, cols, a));
+    return GPMI_OK;
+}
+
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows, int64_t ncols,
                       const double* m_dev, double* dot_out_dev, double* sq_out_dev) {
     if (!V_dev || !m_dev) return fail_arg("gpmi_dev_row_dots: null pointer");

@@ -3,6 +3,7 @@
 // v = L^-1 K_s (and for L^-T), and the fit (K build + Cholesky + LML) they add up to.
 // Data layout: see gpmi_api.hip.
 #include "gpmi_ctx.h"
+#include "gpmi_plan.h"
 
 namespace gpmi {
 
@@ -96,24 +97,7 @@ hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, in
 // and down again over the last columns.  Measured at N = 65536: the exposed panel time drops by
 // 7 ms but the narrower first updates cost 14 ms, so it is off by default.
 std::vector<int64_t> block_schedule(const gpmi_ctx* c, int64_t ncols) {
-    const int64_t NB = c->block(ncols);
-    std::vector<int64_t> w;
-    const bool ramp = c->nb == 0 && c->ramp && NB >= 1024 && ncols >= 8 * NB;
-    const bool up = ramp && (c->ramp & 1), down = ramp && (c->ramp & 2);
-    const int64_t tail = (c->ramp >> 4) ? (c->ramp >> 4) : 3;       // blocks at the end that run at half width
-    int64_t done = 0;
-    while (done < ncols) {
-        int64_t nb = NB;
-        const int64_t left = ncols - done;
-        if (up && w.size() < 2) nb = NB / 4;
-        else if (up && w.size() < 3) nb = NB / 2;
-        else if (down && left <= NB && (c->ramp & 4)) nb = NB / 4;
-        else if (down && left <= tail * NB) nb = NB / 2;
-        nb = std::min(nb, ncols - done);
-        w.push_back(nb);
-        done += nb;
-    }
-    return w;
+    return plan_block_widths(c->block(ncols), ncols, c->nb == 0, c->ramp);      // gpmi_plan.h
 }
 
 // In-place blocked right-looking Cholesky of the leading ncols x ncols block of

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "gpmi_internal.h"
+#include "gpmi_plan.h"
 #include <atomic>
 #include <mutex>
 
@@ -37,8 +38,8 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 #define GPMI_GLB __attribute__((address_space(1)))
 #define GPMI_CONST __attribute__((address_space(4)))
 
-constexpr int DMA_MAX_SM = 128;   // supertile rows a staircase launch can describe (M up to 131072 at S = 8)
-
+// The launch geometry (supertiles, the triangular / staircase enumerations, the block -> tile map) lives in
+// gpmi_plan.h, free of HIP, where a CPU test holds it against brute force under the sanitizers.
 struct GemmDmaDev {
     double* C;
     const double* A;
@@ -74,54 +75,18 @@ struct PersistSlot {
 // PT: GemmDmaDev, in the generic or in the constant (kernel argument) address space
 template <class PT>
 __device__ __forceinline__ bool dma_block_to_tile(const PT& p, int b, int& ti, int& tj) {
-    const int xcd = b & 7;
-    const int w = b >> 3;
-    const int S2 = p.S * p.S;
-    const int s = (w / S2) * 8 + xcd;
-    if (s >= p.nsuper) return false;
-    const int q = w % S2;
-    int si, sj;
-    if (p.tri == 2) {
-        si = 0;
-        while (si + 1 < p.SM && p.sprefix[si + 1] <= s) ++si;
-        sj = s - p.sprefix[si];
-    } else if (p.tri) {
-        si = (int)((sqrtf(8.f * (float)s + 1.f) - 1.f) * 0.5f);
-        while ((si + 1) * (si + 2) / 2 <= s) ++si;
-        while (si * (si + 1) / 2 > s) --si;
-        sj = s - si * (si + 1) / 2;
-    } else {
-        si = s / p.SN;
-        sj = s - si * p.SN;
-        // Supertile s runs on XCD s % 8.  With a row map (or a lower-mode rectangle) the live supertiles of
-        // a row are its leftmost ones, so a fixed column -> XCD assignment (SN % 8 == 0) gives the XCDs that
-        // own the low columns up to 1.5x the work of the others (measured: 54.8 against 67.3 TF/s on a
-        // triangular region).  Rotating the columns by the row index stripes the XCDs diagonally instead.
-        sj += si % p.SN;
-        if (sj >= p.SN) sj -= p.SN;
-    }
-    ti = si * p.S + (q >> p.logS);
-    tj = sj * p.S + (q & (p.S - 1));
-    return ti < p.Tm && tj < p.Tn;
+    return plan_block_to_tile(p, b, ti, tj);
 }
 
 __device__ __forceinline__ bool dma_map_tile(const GemmDmaDev& p, int& ti, int& tj) {
     return dma_block_to_tile(p, blockIdx.x, ti, tj);
 }
 
-constexpr int DMA_TM = 128, DMA_TN = 128;
+constexpr int DMA_TM = PLAN_TILE, DMA_TN = PLAN_TILE;
 // a tile the mode of the launch leaves untouched (above the diagonal, right of its row band)
 template <class PT>
 __device__ __forceinline__ bool dma_tile_live(const PT& p, int ti, int tj) {
-    if (p.lower) {
-        const int64_t min_col = (int64_t)tj * DMA_TN;
-        const int64_t max_row = (int64_t)ti * DMA_TM + DMA_TM - 1;
-        if (min_col > max_row + p.diag_off) return false;
-    }
-    if (p.row_ncols) {
-        if ((int64_t)tj * DMA_TN >= p.row_ncols[ti / p.row_block_tiles]) return false;
-    }
-    return true;
+    return plan_tile_live(p, ti, tj, p.row_ncols);
 }
 constexpr int DMA_STAGE_SLOTS = (DMA_TM + DMA_TN) * 8;     // 16-byte slots per stage (A then B)
 constexpr int DMA_STAGES = 3;
@@ -130,7 +95,27 @@ constexpr int DMA_STAGES = 3;
 //                               2 -> 8 waves of 32 x 64 (512 threads, two waves per SIMD: the
 //                               matrix pipe is fed at its full 64-cycle cadence, which a single
 //                               wave does not reach on fp64 -- measured ~72 cycles per MFMA)
-template <int MI, bool DBG>
+// TICKET: the workgroup stays and draws block numbers from the launch's per-XCD counters (PersistSlot) instead of
+// computing the one block blockIdx names -- see gemm_nt_dma_ticket_kernel below.  The tile code is the same
+// instruction for instruction, so a ticket launch produces the bits of a per-tile launch.
+constexpr unsigned TICKET_NONE = 0xFFFFFFFFu;
+
+// next block number for a workgroup whose blocks run on XCD group `xcd`: from its own group's counter while that lasts
+// (the supertile -> L2 map of the per-tile launch), then from the other groups' (the tail of a launch: an XCD that
+// runs out early takes work from the slower ones instead of idling -- the hardware's static block -> XCD deal cannot)
+__device__ __forceinline__ unsigned ticket_draw(const GemmDmaDev& p, int xcd) {
+    const unsigned per = (unsigned)p.nblocks >> 3;
+#pragma unroll 1
+    for (int t = 0; t < 8; ++t) {
+        const int x = (xcd + t) & 7;
+        if (t && __hip_atomic_load(&p.slot->ctr[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= per) continue;
+        const unsigned w = atomicAdd(&p.slot->ctr[x], 1u);
+        if (w < per) return w * 8u + (unsigned)x;
+    }
+    return TICKET_NONE;
+}
+
+template <int MI, bool DBG, bool TICKET = false>
 __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
     constexpr int NWAVES = 16 / MI;                 // 4 or 8
     constexpr int DPW = 32 / NWAVES;                // DMA wave-instructions per wave per K step (8 or 4)
@@ -138,20 +123,33 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
     constexpr int NFR = MI + 4;                     // fragment reads per half step
     const int dbg = DBG ? p.dbg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    int ti, tj;
-    if (!dma_map_tile(p, ti, tj)) return;
-    if (p.lower) {
-        const int64_t min_col = (int64_t)tj * DMA_TN;
-        const int64_t max_row = (int64_t)ti * DMA_TM + DMA_TM - 1;
-        if (min_col > max_row + p.diag_off) return;
+    const int tid = threadIdx.x;
+    // ticket form: mailbox of two ints behind the ring (one barrier per tile: the writer alternates between them)
+    volatile GPMI_LDS int* mbox = (volatile GPMI_LDS int*)(smem_raw + DMA_STAGES * DMA_STAGE_SLOTS * 16);
+    unsigned blk = blockIdx.x, nxt_blk = TICKET_NONE;
+    int par = 0;
+    if constexpr (TICKET) {
+        if (tid == 0) mbox[0] = (int)ticket_draw(p, (int)(blockIdx.x & 7));
+        __syncthreads();
+        blk = (unsigned)__builtin_amdgcn_readfirstlane(mbox[0]);
+        par = 1;
     }
-    if (p.row_ncols) {
-        if ((int64_t)tj * DMA_TN >= p.row_ncols[ti / p.row_block_tiles]) return;
+  for (;;) {
+    int ti = 0, tj = 0;
+    bool live;
+    if constexpr (TICKET) {
+        if (blk == TICKET_NONE) break;
+        live = dma_block_to_tile(p, (int)blk, ti, tj) && dma_tile_live(p, ti, tj);
+        live = __builtin_amdgcn_readfirstlane(live ? 1 : 0) != 0;
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        tj = __builtin_amdgcn_readfirstlane(tj);
+    } else {
+        live = dma_map_tile(p, ti, tj) && dma_tile_live(p, ti, tj);
+        if (!live) return;
     }
-
+   if (live) {
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
     if (DBG && (dbg & 16)) st0 = clock64();
-    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = (wave >> 1) * (16 * MI);
@@ -299,6 +297,10 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
 #undef GPMI_FENCE
 
     if (DBG && (dbg & 16)) st2 = clock64();
+    // ticket form: the successor's number is requested here, in front of the C loads, and arrives with them
+    if constexpr (TICKET) {
+        if (tid == 0) nxt_blk = ticket_draw(p, (int)(blockIdx.x & 7));
+    }
     // epilogue: C -= acc in 16-row bands (nothing else runs on this SIMD, so it must not
     // cost a memory round trip per band)
     double* Cg = p.C + ((int64_t)ti * DMA_TM + wr) * p.ldc + (int64_t)tj * DMA_TN + wc;
@@ -347,6 +349,35 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
             o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st3 - st2; o[3] = st4 - st3;
         }
     }
+   }  // live
+    if constexpr (!TICKET) {
+        return;
+    } else {
+        // hand the successor's number to the workgroup.  The barrier also separates this tile's last LDS reads from
+        // the next tile's first DMA writes (all of a tile's fragment reads are issued before its last in-loop barrier,
+        // so nothing is pending here anyway).
+        if (tid == 0) {
+            if (!live) nxt_blk = ticket_draw(p, (int)(blockIdx.x & 7));
+            mbox[par] = (int)nxt_blk;
+        }
+        __syncthreads();
+        blk = (unsigned)__builtin_amdgcn_readfirstlane(mbox[par]);
+        par ^= 1;
+    }
+  }  // tiles
+    if constexpr (TICKET) {
+        // the last workgroup out puts the counters back (as the persistent form below)
+        if (tid == 0) {
+            __threadfence();
+            const unsigned old = atomicAdd(&p.slot->done, 1u);
+            if (old == gridDim.x - 1) {
+#pragma unroll
+                for (int x = 0; x < 8; ++x) p.slot->ctr[x] = 0;
+                p.slot->done = 0;
+                __threadfence();
+            }
+        }
+    }
 }
 
 template <int MI, bool DBG>
@@ -358,6 +389,23 @@ __global__ __launch_bounds__(1024 / MI, (MI == 4) ? 2 : 3) void gemm_nt_dma_kern
 // that a kernel trace lists those launches apart from the in-panel and solve-sweep updates.
 __global__ __launch_bounds__(512, 3) void chol_trailing_update_dma_kernel(const GemmDmaDev p) {
     gemm_nt_dma_body<2, false>(p);
+}
+
+// ---------------------------------------------------------------------------
+// Ticket form of the 8-wave kernel: gridDim.x = (CUs per XCD - r) x 8 workgroups (one per CU: 96 KiB of LDS each)
+// stay for the whole launch and draw their tiles from the launch's per-XCD counters.  Unlike the persistent form
+// below it keeps NOTHING across tiles -- same registers as the per-tile kernel (the C tile is not prefetched), so
+// the small-LDS panel kernels of the other stream still fit on a CU beside it -- and what it buys is placement:
+//   * r CUs per XCD are never touched by the launch (`reserve`): a panel kernel that needs a whole CU (potrf128:
+//     2 x 123 registers per SIMD lane) finds one at once instead of waiting for the update's next round boundary;
+//   * an XCD whose own blocks are used up draws from the others' counters, so the tail of a launch is shared by
+//     all CUs, not by the CUs of the XCD the static deal left with the most work.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 3) void gemm_nt_dma_ticket_kernel(const GemmDmaDev p) {
+    gemm_nt_dma_body<2, false, true>(p);
+}
+__global__ __launch_bounds__(512, 3) void chol_trailing_update_ticket_kernel(const GemmDmaDev p) {
+    gemm_nt_dma_body<2, false, true>(p);
 }
 
 // ---------------------------------------------------------------------------
@@ -829,7 +877,8 @@ static PersistPool* persist_pool() {
         if (hipMemset(q, 0, sizeof(PersistSlot) * PersistPool::SLOTS) != hipSuccess) { (void)hipFree(q); return nullptr; }
         pl.groups = (prop.multiProcessorCount / 8) * 8;
         if (pl.groups < 8) { (void)hipFree(q); return nullptr; }
-        const void* fns[] = {(const void*)gemm_nt_dma_persist_kernel, (const void*)chol_trailing_update_persist_kernel};
+        const void* fns[] = {(const void*)gemm_nt_dma_persist_kernel, (const void*)chol_trailing_update_persist_kernel,
+                             (const void*)gemm_nt_dma_ticket_kernel, (const void*)chol_trailing_update_ticket_kernel};
         for (const void* f : fns)
             if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(DMA_STAGES * DMA_STAGE_SLOTS * 16 + 16)) != hipSuccess) { (void)hipFree(q); return nullptr; }
@@ -853,44 +902,14 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     p.b_block_off = a.b_block_off;
     p.b_block_tiles = a.b_block_off ? (int)(a.b_block_rows / 128) : 1;
     if (a.b_block_off && (a.b_block_rows <= 0 || a.b_block_rows % 128)) return hipErrorInvalidValue;
-    p.tri = (a.lower && a.diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
-    const bool stairs = a.row_ncols && a.row_ncols_host && a.row_bands > 0 && !a.lower;
-    // supertile edge: 8 tiles, but never wider than the launch -- a strip of Tn = 1 (a panel-internal update of 128
-    // columns) enumerated in 8 x 8 supertiles is seven dead workgroups for every live one, and a dead workgroup still has
-    // to be handed a CU with 96 KiB of free LDS before it can return (32768 x 128 x 128: 88 us, beside a trailing update
-    // each of them waits for a tile to finish)
-    int S = 8;
-    while (S > 1 && (S > p.Tn || S > p.Tm)) S >>= 1;
-    for (;; S >>= 1) {
-        const int SM = (p.Tm + S - 1) / S, SN = (p.Tn + S - 1) / S;
-        int ns = p.tri ? SM * (SM + 1) / 2 : SM * SN;
-        bool use_stairs = false;
-        if (stairs && SM <= DMA_MAX_SM) {
-            // live supertiles per supertile row: up to the widest band of the row
-            int tot = 0;
-            p.sprefix[0] = 0;
-            for (int si = 0; si < SM; ++si) {
-                int64_t widest = 0;
-                for (int ti = si * S; ti < std::min((si + 1) * S, p.Tm); ++ti) {
-                    const int band = std::min(ti / p.row_block_tiles, a.row_bands - 1);
-                    widest = std::max<int64_t>(widest, a.row_ncols_host[band]);
-                }
-                const int64_t live = std::min<int64_t>(SN, (widest + (int64_t)S * 128 - 1) / ((int64_t)S * 128));
-                tot += (int)live;
-                p.sprefix[si + 1] = tot;
-            }
-            ns = tot;
-            use_stairs = true;
-        }
-        if (ns >= 32 || S == 1) {
-            p.S = S; p.SM = SM; p.SN = SN; p.nsuper = ns;
-            if (use_stairs) p.tri = 2;
-            break;
-        }
-    }
+    TilePlan plan;
+    if (!plan_tiles(plan, p.Tm, p.Tn, a.lower, a.diag_off, a.row_ncols != nullptr, a.row_ncols_host, a.row_bands,
+                    p.row_block_tiles))
+        return hipErrorInvalidValue;
+    p.S = plan.S; p.logS = plan.logS; p.SM = plan.SM; p.SN = plan.SN; p.tri = plan.tri; p.nsuper = plan.nsuper;
+    if (plan.tri == 2) std::copy(plan.sprefix, plan.sprefix + plan.SM + 1, p.sprefix);
     if (p.nsuper == 0) return hipSuccess;
-    p.logS = (p.S == 8) ? 3 : (p.S == 4) ? 2 : (p.S == 2) ? 1 : 0;
-    const int nblocks = ((p.nsuper + 7) / 8) * 8 * p.S * p.S;
+    const int nblocks = plan.nblocks;
     constexpr size_t lds = (size_t)DMA_STAGES * DMA_STAGE_SLOTS * 16;
     static PerDeviceOnce once;
     const hipError_t ea = once.run([&]() -> hipError_t {
@@ -913,6 +932,21 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     // and the chip to themselves: resident workgroups (216 registers per lane, two waves per SIMD) leave no room on a
     // CU for the panel kernels of the other stream, which would then wait for the whole launch instead of a tile
     // (lookahead with both forms: N = 16384 fit + predict 39.8 against 42.9 ms)
+    // ticket form (option gemm_ticket: 1 for the Cholesky's trailing updates while two streams are busy, 2 for every
+    // launch of at least one round; gemm_reserve CUs per XCD stay untouched)
+    if (tn.gemm_dma_waves == 8 && !p.dbg &&
+        (tn.gemm_ticket >= 2 || (tn.gemm_ticket == 1 && a.role == 1 && gemm_two_streams_active()))) {
+        PersistPool* pool = persist_pool();
+        const int reserve = std::max(0, std::min(tn.gemm_reserve, pool ? pool->groups / 8 - 1 : 0));
+        if (pool && nblocks >= pool->groups) {
+            p.slot = pool->next();
+            const int groups = pool->groups - 8 * reserve;
+            constexpr size_t ldst = lds + 16;          // ring + mailbox
+            if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_ticket_kernel, dim3(groups), dim3(512), ldst, s, p);
+            else hipLaunchKernelGGL(gemm_nt_dma_ticket_kernel, dim3(groups), dim3(512), ldst, s, p);
+            return hipGetLastError();
+        }
+    }
     if (tn.gemm_persist && tn.gemm_dma_waves == 8 && !p.dbg && p.nchunks >= 16 && !gemm_two_streams_active()) {
         // no pool (its allocation or the opt-in failed, or an unusual device): the persistent form is an optimisation,
         // the per-tile launch below computes the same bits

@@ -22,6 +22,7 @@
 #include <algorithm>
 
 #include "gpmi_internal.h"
+#include "gpmi_plan.h"
 
 namespace gpmi {
 
@@ -303,40 +304,14 @@ hipError_t launch_gemm_nt(hipStream_t s, const GemmArgs& a) {
 }
 
 double gemm_nt_flops(const GemmArgs& a) {
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0.;
-    const int TN = (a.N % 128 == 0) ? 128 : 64;
-    const int64_t Tm = a.M / 128, Tn = a.N / TN;
-    int64_t tiles = 0;
-    for (int64_t ti = 0; ti < Tm; ++ti) {
-        if (!a.lower) { tiles += Tn; continue; }
-        // tiles tj with tj*TN <= ti*128 + 127 + diag_off
-        int64_t lim = (ti * 128 + 127 + a.diag_off);
-        if (lim < 0) continue;
-        int64_t cnt = lim / TN + 1;
-        tiles += cnt < Tn ? cnt : Tn;
-    }
-    return 2.0 * (double)tiles * 128.0 * TN * (double)a.K;
+    return plan_tile_flops(a.M, a.N, a.K, a.lower, a.diag_off);
 }
 
 // Algorithmic flops of a lower-mode update: 2 K per element on or below the diagonal
 // (col <= row + diag_off) of the first `real_rows` rows -- what the Cholesky needs, as opposed to
-// what the tiles compute (whole diagonal tiles, padding rows).
+// what the tiles compute (whole diagonal tiles, padding rows).  (gpmi_plan.h)
 double gemm_nt_algorithmic_flops(const GemmArgs& a, int64_t real_rows) {
-    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return 0.;
-    const int64_t rows = std::min<int64_t>(a.M, real_rows);
-    if (!a.lower) return 2.0 * (double)rows * (double)a.N * (double)a.K;
-    // row r reaches min(N, r + diag_off + 1) columns
-    double elems = 0.;
-    const int64_t r_full = std::max<int64_t>(0, a.N - 1 - a.diag_off);        // first row that reaches all N columns
-    const int64_t r_first = std::max<int64_t>(0, -a.diag_off);              // first row that reaches column 0
-    const int64_t tri_end = std::min(rows, r_full);
-    if (tri_end > r_first) {
-        const double n = (double)(tri_end - r_first);
-        const double first = (double)(r_first + a.diag_off + 1);
-        elems += n * first + n * (n - 1) / 2.0;
-    }
-    if (rows > r_full) elems += (double)(rows - std::max(r_full, (int64_t)0)) * (double)a.N;
-    return 2.0 * elems * (double)a.K;
+    return plan_algorithmic_flops(a.M, a.N, a.K, a.lower, a.diag_off, real_rows);
 }
 
 }  // namespace gpmi

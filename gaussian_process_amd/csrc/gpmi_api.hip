@@ -112,6 +112,12 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->tune.gemm_small_dma = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_persist")) {
         c->tune.gemm_persist = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_ticket")) {
+        if (value < 0 || value > 2) return fail_arg("gemm_ticket must be 0 (off), 1 (trailing updates under lookahead) or 2 (every launch)");
+        c->tune.gemm_ticket = (int)value;
+    } else if (!strcmp(name, "gemm_reserve")) {
+        if (value < 0 || value > 24) return fail_arg("gemm_reserve must be in 0..24 (CUs per XCD)");
+        c->tune.gemm_reserve = (int)value;
     } else if (!strcmp(name, "trsv_vinv")) {
         if (value < 0 || value > 2) return fail_arg("trsv_vinv must be 0 (16 x 16 rounds), 1 (one launch per block) or 2 (one launch)");
         c->tune.trsv_vinv = (int)value;
@@ -516,8 +522,12 @@ int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
     c->span_end(sp);
     std::vector<double> part((size_t)nblk * 2);
     HIP_TRY(hipMemcpyAsync(part.data(), a.partial, part.size() * 8, hipMemcpyDeviceToHost, s));
+    int gave_up = 0;      // the one-launch backward solve's "a poll gave up" word, as gpmi_get_alpha reads it
+    if (c->factor_fused && tuning().trsv_vinv >= 2)
+        HIP_TRY(hipMemcpyAsync(&gave_up, c->flag.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->timers_collect();
+    if (gave_up) return fail_runtime(hipErrorUnknown, "gpmi_lml_grad: the single-launch backward solve gave up waiting for a block");
     double sl = 0.0, ss = 0.0;
     for (int64_t b = 0; b < nblk; ++b) { sl += part[2 * b]; ss += part[2 * b + 1]; }   // fixed order
     *d_ell = .5 * sl;

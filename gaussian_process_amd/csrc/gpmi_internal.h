@@ -19,6 +19,8 @@ struct Tuning {
     int gemm_use_dma = 1;       // LDS-DMA GEMM for launches with >= 256 tiles
     int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
     int gemm_persist = 1;       // resident workgroups that chain the K loops of consecutive tiles (launches with >= 2 rounds of tiles)
+    int gemm_ticket = 0;        // ticket form of the per-tile kernel (resident workgroups, tiles drawn from counters, no state across tiles): 1 Cholesky trailing updates under lookahead, 2 every launch of at least one round
+    int gemm_reserve = 0;       // ticket form: CUs per XCD the launch leaves untouched (for the panel kernels of the other stream)
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always
     int rbf_blocks = 16384;     // persistent blocks of the register-path K build
@@ -197,6 +199,12 @@ hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nro
                          const double* x, double* y, double* scratch);
 // out2[0..1] += the sums of the even / odd entries of part (n pairs), fixed order
 hipError_t launch_sum_pairs(hipStream_t s, const double* part, int64_t n, double* out2);
+// out[i] = (base ? base[i] : 0) + scale * sum_{q < count} in[q * stride + i], i < n; the sum runs in index order
+hipError_t launch_sum_fixed(hipStream_t s, const double* in, int64_t count, int64_t stride, int64_t n,
+                            const double* base, double scale, double* out);
+// Y (rows x cols) += a * X
+hipError_t launch_axpy2d(hipStream_t s, double* Y, int64_t ldy, const double* X, int64_t ldx, int64_t rows,
+                         int64_t cols, double a);
 // fill helpers
 hipError_t launch_fill_rows(hipStream_t s, double* A, int64_t ld, int64_t nrows, int64_t ncols,
                             double value);

@@ -597,7 +597,8 @@ hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X
 }
 
 hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n, double* vside) {
-    if (n <= 0 || n % PB || ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15)) return hipErrorInvalidValue;
+    if (n <= 0 || n % PB || ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(vside) & 15))
+        return hipErrorInvalidValue;
     hipError_t e = panel_mfma_attrs();
     if (e != hipSuccess) return e;
     if (vside) {

@@ -399,16 +399,22 @@ hipError_t launch_trsv_lt_vinv(hipStream_t s, const double* L, int64_t ld, doubl
 // Summation order is fixed (rows in order inside a wave's 16, chunks bottom-up, the four waves' partials in order),
 // so the result does not depend on timing.
 constexpr unsigned long long TRSV_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
-constexpr int TRSV_MAX_POLLS = 1 << 22;
+// A wait is bounded by wall time, not by a poll count: the queue has to make progress for the chain to advance
+// (workgroups are dispatched in index order), and a co-tenant that holds the CUs for a while -- another process on
+// the card, eight thread-ranks on one GPU -- must read as a slow solve, not as an error.  wall_clock64 ticks at
+// 100 MHz on gfx950: 10 s.
+constexpr unsigned long long TRSV_MAX_WAIT_TICKS = 1000000000ull;
 
 __device__ __forceinline__ double trsv_poll(const double* p, int* err) {
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
     unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v != TRSV_SENTINEL) return __longlong_as_double((long long)v);
+    const unsigned long long t0 = wall_clock64();
     int polls = 0;
     while (v == TRSV_SENTINEL) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (++polls > TRSV_MAX_POLLS) { *err = 1; v = 0x7FF8000000000000ull; break; }
+        if ((++polls & 1023) == 0 && wall_clock64() - t0 > TRSV_MAX_WAIT_TICKS) { *err = 1; v = 0x7FF8000000000000ull; break; }
     }
     return __longlong_as_double((long long)v);
 }
@@ -531,6 +537,8 @@ __global__ __launch_bounds__(256, 2) void trsv_lt_chain_kernel(const double* __r
 hipError_t launch_trsv_lt_chain(hipStream_t s, const double* L, int64_t ld, const double* vside, const double* m,
                                 double* xout, int64_t n, int* err_dev) {
     if (n <= 0 || n % 128 || ld % 2 || n / 128 > (1 << 20) || !err_dev || !vside) return hipErrorInvalidValue;
+    // the kernel reads L, vside and its LDS staging with 16-byte loads: a view with an odd column offset is refused
+    if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(vside) & 15)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(xout, 0xFF, (size_t)n * 8, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(trsv_lt_chain_kernel, dim3((unsigned)(n / 128)), dim3(256), 0, s, L, ld, vside, m, xout, (int)(n / 128),
@@ -651,6 +659,44 @@ __global__ void sum_pairs_kernel(const double* part, int64_t n, double* out2) {
 
 hipError_t launch_sum_pairs(hipStream_t s, const double* part, int64_t n, double* out2) {
     hipLaunchKernelGGL(sum_pairs_kernel, dim3(1), dim3(256), 0, s, part, n, out2);
+    return hipGetLastError();
+}
+
+// ---- fixed-order reductions of the partitioned path (dist.py) -------------------------------
+// out[i] = (base ? base[i] : 0) + scale * (in[i] + in[stride + i] + ... + in[(count - 1) * stride + i]), i < n: the
+// `count` contributions are added one after the other in index order, whatever the launch geometry -- one thread per
+// i, no tree -- so every rank that sums the same gathered contributions gets the same bits (the per-rank partial
+// sums of the distributed backward solve and of the log-determinant).  out may alias base.
+__global__ void sum_fixed_kernel(const double* in, int64_t count, int64_t stride, int64_t n, const double* base,
+                                 double scale, double* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.;
+    for (int64_t q = 0; q < count; ++q) s += in[q * stride + i];
+    out[i] = base ? base[i] + scale * s : scale * s;
+}
+
+hipError_t launch_sum_fixed(hipStream_t s, const double* in, int64_t count, int64_t stride, int64_t n,
+                            const double* base, double scale, double* out) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_fixed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, count, stride, n, base,
+                       scale, out);
+    return hipGetLastError();
+}
+
+// Y (rows x cols, ldy) += a * X (rows x cols, ldx): elementwise, one rounding per element (a * x is exact for a = +-1)
+__global__ void axpy2d_kernel(double* Y, int64_t ldy, const double* X, int64_t ldx, int64_t cols, double a) {
+    const int64_t r = blockIdx.y;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < cols; j += (int64_t)gridDim.x * blockDim.x)
+        Y[r * ldy + j] += a * X[r * ldx + j];
+}
+
+hipError_t launch_axpy2d(hipStream_t s, double* Y, int64_t ldy, const double* X, int64_t ldx, int64_t rows,
+                         int64_t cols, double a) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    unsigned gx = (unsigned)((cols + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(axpy2d_kernel, dim3(gx, (unsigned)rows), dim3(256), 0, s, Y, ldy, X, ldx, cols, a);
     return hipGetLastError();
 }
 

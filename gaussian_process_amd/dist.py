@@ -25,7 +25,8 @@ updates its own column blocks; mean / variance are ordered sums of per-rank part
 row dots.  No collective carries more than the panel column / one solved block.
 
 torch is used for device memory, strided copies, streams and torch.distributed only;
-all arithmetic goes through the C-ABI block primitives (`HipBlockOps`).  The driver
+all arithmetic -- the three small reductions over gathered partials included (gpmi_dev_sum_fixed,
+gpmi_dev_axpy2d) -- goes through the C-ABI block primitives (`HipBlockOps`).  The driver
 takes the primitives as an object so that the CPU tests (gloo, world_size 2) can run
 the same schedule on NumPy stand-ins defined under tests/.
 """
@@ -64,15 +65,19 @@ class TorchComm:
     def _src(self, r):
         return dist.get_global_rank(self.group, r) if self.group is not None else r
 
-    def broadcast(self, t, src):
+    # `tag` names what a collective carries -- ("panel", k), ("Lkk", k), ("vblock", k), ... -- and is ignored here: a
+    # stand-in communicator (replay.ReplayComm: one rank of G alone on a GPU) uses it to know which bytes the absent
+    # ranks would have delivered
+    def broadcast(self, t, src, tag=None):
         dist.broadcast(t, src=self._src(src), group=self.group)
 
-    def all_gather(self, out, inp):
+    def all_gather(self, out, inp, tag=None):
         """out (size * len(inp)) <- every rank's inp, in rank order"""
         dist.all_gather_into_tensor(out, inp, group=self.group)
 
-    def all_reduce(self, t, op="sum"):
-        dist.all_reduce(t, op=dist.ReduceOp.MIN if op == "min" else dist.ReduceOp.SUM, group=self.group)
+    def all_reduce(self, t, op="sum", tag=None):
+        ops = {"min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX, "sum": dist.ReduceOp.SUM}
+        dist.all_reduce(t, op=ops[op], group=self.group)
 
     def describe(self):
         """the backend and the RCCL / NCCL knobs in effect (bench line)"""
@@ -202,6 +207,17 @@ class HipBlockOps:
         check(self.lib.gpmi_dev_grad_trace(self._stream(), self._p(X), N, d, row0, nrows, self._p(alpha_r), self._p(alpha_c),
                                            self._p(Kinv), self._ld(Kinv), float(kinv_sign), float(sigma), float(ell),
                                            self._p(partial), self._p(out2)))
+
+    def sum_fixed(self, inp, count, stride, n, out, base=None, scale=1.0):
+        """out[i] = (base[i] if base is not None else 0) + scale * sum_{q < count} inp[q * stride + i], added in index order"""
+        check(self.lib.gpmi_dev_sum_fixed(self._stream(), self._p(inp), int(count), int(stride), int(n),
+                                          self._p(base) if base is not None else None, float(scale), self._p(out)))
+
+    def axpy2d(self, Y, X, a):
+        """Y += a * X (2-D views of equal shape)"""
+        assert Y.shape == X.shape and Y.dim() == 2
+        check(self.lib.gpmi_dev_axpy2d(self._stream(), self._p(Y), self._ld(Y), self._p(X), self._ld(X), Y.shape[0], Y.shape[1],
+                                       float(a)))
 
     def set_concurrent(self, on):
         check(self.lib.gpmi_dev_set_concurrent(1 if on else 0))
@@ -384,8 +400,8 @@ class DistGP:
         self.X = torch.from_numpy(X).to(self.dev)
         self.y = torch.from_numpy(y).to(self.dev)
         if self.coll:
-            self.comm.broadcast(self.X, 0)
-            self.comm.broadcast(self.y, 0)
+            self.comm.broadcast(self.X, 0, tag=("X",))
+            self.comm.broadcast(self.y, 0, tag=("y",))
         self.A = self._tensor(max(self.rows, 1), self.ld)
         self.Lkk = self._tensor(NB, NB)
         cmax = max(self._nblocks(r) for r in range(G))
@@ -559,7 +575,7 @@ class DistGP:
             with self._timed("pack", None):
                 self.send[:cnt * NB * NB].view(cnt * NB, NB).copy_(A[r0:r0 + cnt * NB, c0:c0 + NB])
         with self._timed("allgather", None):
-            self.comm.all_gather(buf[:G * cmax * NB * NB], self.send[:cmax * NB * NB])
+            self.comm.all_gather(buf[:G * cmax * NB * NB], self.send[:cmax * NB * NB], tag=("panel", k))
 
     def _pblock(self, k, buf, i):
         """block k + 1 + i of panel column k as an NB x NB tensor"""
@@ -601,7 +617,7 @@ class DistGP:
                 self.Lkk.copy_(diag)
         if self.coll:
             with self._timed("bcast", None):
-                self.comm.broadcast(self.Lkk, owner)
+                self.comm.broadcast(self.Lkk, owner, tag=("Lkk", k))
         ls = self._lstart(k)
         r0 = ls * NB
         m = self.rows - r0
@@ -635,7 +651,7 @@ class DistGP:
                     Lk[0].copy_(diag)
             if self.coll:
                 with self._timed("bcast", None):
-                    self.comm.broadcast(Lk[0], 0)
+                    self.comm.broadcast(Lk[0], 0, tag=("Lkk", 0))
         ev_bcast = self._record("crit")
         ev_panel_prev = None                             # side-stream work of step k-1 (last reader of Lk[(k+1) % 2])
         import time
@@ -681,7 +697,7 @@ class DistGP:
             with self._on("crit"):                       # queued behind the owner's potrf on this stream
                 if self.coll:
                     with self._timed("bcast", None):
-                        self.comm.broadcast(Lk[(k + 1) % 2], (k + 1) % G)
+                        self.comm.broadcast(Lk[(k + 1) % 2], (k + 1) % G, tag=("Lkk", k + 1))
             ev_bcast = self._record("crit")
             with self._timed("stall_panel", "main"):      # elapsed between these two events = main-stream time lost to the panel chain
                 self._wait("main", ev_panel)
@@ -778,7 +794,7 @@ class DistGP:
                 self._order(first_is_side=True)               # main waits for the last panel
         # not-PD: smallest failing global column over all ranks
         if self.coll:
-            self.comm.all_reduce(self.info, "min")
+            self.comm.all_reduce(self.info, "min", tag=("info",))
         info = int(self.info.item())
         if info != INT64_MAX and info < self.N:
             err = np.linalg.LinAlgError("Matrix is not positive definite")
@@ -791,11 +807,14 @@ class DistGP:
         if self.yrow is not None:
             ops.logdiag_sumsq(None, 0, A[self.yrow], self.N, self.red[self.nloc])
             self.m.copy_(A[self.yrow, :self.Np])
-        part = torch.stack([self.red[:max(self.nloc, 1), 0].sum(), self.red[self.nloc, 1]])
+        # this rank's piece: its log-diagonal sums added in block order (fixed order, own kernel), m^T m on the y rank
+        part = self._tensor(2)
+        ops.sum_fixed(self.red, self.nloc, 2, 1, part[0:1])
+        part[1:2].copy_(self.red[self.nloc, 1:2])
         if self.coll:
             allp = self._tensor(G * 2)
-            self.comm.all_gather(allp, part.contiguous())
-            self.comm.broadcast(self.m, self.ry)
+            self.comm.all_gather(allp, part, tag=("lml",))
+            self.comm.broadcast(self.m, self.ry, tag=("m",))
         else:
             allp = part
         allp = allp.view(G, 2).cpu().numpy()
@@ -816,7 +835,7 @@ class DistGP:
         self.n_p = _round_up(self.n, 128)
         self.Xs = torch.from_numpy(Xs).to(self.dev)
         if self.coll:
-            self.comm.broadcast(self.Xs, 0)
+            self.comm.broadcast(self.Xs, 0, tag=("Xs",))
         self.ldv = max(self.nloc, 1) * self.NB + self.ld_pad
         self.V = self._tensor(self.n_p, self.ldv)
         self.Xk = [self._tensor(self.n_p, self.NB) for _ in range(2)]
@@ -852,7 +871,7 @@ class DistGP:
                             Xk.copy_(blk)
                 if self.coll and k < T - 1:
                     with self._timed("bcast_v", None):
-                        self.comm.broadcast(Xk, k % G)
+                        self.comm.broadcast(Xk, k % G, tag=("vblock", k))
 
             def xk_view(k):
                 return self.Xk[k % 2] if self.coll else V[:, k * NB:(k + 1) * NB]
@@ -895,7 +914,7 @@ class DistGP:
             ops.row_dots(V, self.nloc * NB, self.m_loc, self.dots[0], self.dots[1])
         if self.coll:
             alld = self._tensor(G * 2 * self.n_p)
-            self.comm.all_gather(alld, self.dots.view(-1))
+            self.comm.all_gather(alld, self.dots.view(-1), tag=("dots",))
         else:
             alld = self.dots
         alld = alld.view(G, 2, self.n_p).cpu().numpy()
@@ -930,9 +949,9 @@ class DistGP:
         if self.nloc:
             ops.gemm_nt(Gm[:, :n_p], self.V[:, :self.nloc * NB], self.V[:, :self.nloc * NB])     # Gm = -v_loc^T v_loc
         if self.coll:
-            self.comm.all_reduce(Gm, "sum")
+            self.comm.all_reduce(Gm, "sum", tag=("vtv",))
         self._cov_rows(self.Xs, self.n, 0, n_p, n_p, float(jitter), P)
-        P[:, :n_p].add_(Gm[:, :n_p])
+        ops.axpy2d(P[:, :n_p], Gm[:, :n_p], 1.0)
         info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         ops.potrf_block(P[:, :n_p], 0, info)
         bad = int(info.item())
@@ -978,7 +997,7 @@ class DistGP:
             if k == T - 1:
                 break
             if self.coll:
-                self.comm.broadcast(Xk[:m], k % G)
+                self.comm.broadcast(Xk[:m], k % G, tag=("ublock", k))
             src = Xk[:m] if self.coll else U[:m, (k // G) * NB:(k // G + 1) * NB]
             ls = self._lstart(k)
             if self.nloc - ls > 0:
@@ -1000,7 +1019,7 @@ class DistGP:
                                partial, out2)
         if self.coll:
             allp = self._tensor(G * 2)
-            self.comm.all_gather(allp, out2)
+            self.comm.all_gather(allp, out2, tag=("grad",))
         else:
             allp = out2
         allp = allp.view(G, 2).cpu().numpy()
@@ -1040,16 +1059,15 @@ class DistGP:
                     part.zero_()
             if self.coll:
                 with self._timed("alpha_gather", None):
-                    self.comm.all_gather(allp, part)
+                    self.comm.all_gather(allp, part, tag=("alpha_part", k))
             else:
                 allp.copy_(part)
             if self.rank == k % G:
                 li = k // G
-                rhs.copy_(self.m[c0:c0 + NB])
-                # one reduction kernel over the G contributions (a fixed tree for a given G and nb: the same
-                # bits on every run), not G tiny launches on the latency chain of the block
+                # rhs = m_k - (part_0 + part_1 + ... ): ONE launch of the library's own fixed-order sum (contributions added
+                # in rank order whatever the launch geometry: the same bits on every run and every rank)
                 with self._timed("alpha_solve", None):
-                    rhs.sub_(allp.view(G, NB).sum(dim=0))
+                    ops.sum_fixed(allp, G, NB, NB, rhs, base=self.m[c0:c0 + NB], scale=-1.0)
                     if self._cuda():             # the one-launch backward solve keeps each block's inverses in a side buffer
                         vs = self._vside.get(li)
                         if vs is None:
@@ -1066,14 +1084,22 @@ class DistGP:
         send[:self.nloc * NB].copy_(aloc[:self.nloc * NB])
         if self.coll:
             recv = self._tensor(G * cmax * NB)
-            self.comm.all_gather(recv, send)
+            self.comm.all_gather(recv, send, tag=("alpha_full",))
         else:
             recv = send
         R = recv.view(G, cmax, NB).cpu().numpy()
+        # a poll of the one-launch diagonal-block solve that gave up (non-finite factor) is known to the block's owner only:
+        # the flag is max-reduced so that EVERY rank raises, none walks on to the next collective with a NaN alpha
         err = getattr(ops, "_err", None)
-        if err is not None and int(err[0].item()) != 0:
-            err.zero_()
-            raise RuntimeError("DistGP.alpha: the one-launch backward solve gave up waiting for a block (non-finite factor?)")
+        if self._cuda():
+            if err is None:
+                err = ops._err = torch.zeros(16, dtype=torch.int32, device=self.dev)
+            flag = err[0:1].to(torch.float64)
+            if self.coll:
+                self.comm.all_reduce(flag, "max", tag=("alpha_err",))
+            if float(flag.item()) != 0.0:
+                err.zero_()
+                raise RuntimeError("DistGP.alpha: the one-launch backward solve gave up waiting for a block (non-finite factor?)")
         out = np.empty(self.Np)
         for b in range(T):
             out[b * NB:(b + 1) * NB] = R[b % G, b // G]

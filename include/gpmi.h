@@ -305,7 +305,11 @@ int gpmi_dev_trsv_lt_vinv(void* stream, double* L_dev, int64_t ld, double* b_dev
  * between two blocks.  vside_dev: n * 128 doubles owned by the caller; invert != 0 first fills it with the inverses of the
  * 128 x 128 diagonal blocks (row-major, one launch; also written into the blocks' upper triangles as above), later calls
  * on the same factored block pass 0 and the same buffer.  m_dev is only read; x_dev must not alias it.  err_dev: one int
- * the kernel sets to 1 if a poll gave up (non-finite factor); zero it before the call.  a5 (GP_regression.py:140). */
+ * the kernel sets to 1 if a wait gave up (non-finite factor); zero it before the call.  L_dev and vside_dev must be
+ * 16-byte aligned (the kernel reads both with 16-byte loads; an odd column offset of a view is refused).  The chain
+ * advances only while the queue makes progress: workgroup b waits for workgroups < b, which the hardware dispatches
+ * first; a wait is bounded by wall time (10 s), so a co-tenant that holds the card for a while reads as a slow solve,
+ * never as a wrong one.  a5 (GP_regression.py:140). */
 int gpmi_dev_trsv_lt_chain(void* stream, double* L_dev, int64_t ld, double* vside_dev, const double* m_dev, double* x_dev,
                            int64_t n, int invert, int* err_dev);
 /* on != 0: the block primitives called from this thread run beside a trailing update on another stream (lookahead)
@@ -324,6 +328,18 @@ int gpmi_dev_grad_trace(void* stream, const double* X_dev, int64_t N, int64_t d,
 int gpmi_dev_row_dots(void* stream, const double* V_dev, int64_t ld, int64_t nrows,
                       int64_t ncols, const double* m_dev, double* dot_out_dev,
                       double* sq_out_dev);
+
+/* out[i] = (base_dev ? base_dev[i] : 0) + scale * (in[i] + in[stride + i] + ... + in[(count - 1) * stride + i]),
+ * i < n, the contributions added one after the other in index order (no reduction tree): the partitioned path's sums
+ * over gathered per-rank partials -- the right-hand side m_k - sum_r part_r of the distributed backward solve
+ * (GP_regression.py:140), the log-determinant pieces (tune_hyperparms_regression.py:312) -- come out with the same
+ * bits on every rank.  out_dev may alias base_dev. */
+int gpmi_dev_sum_fixed(void* stream, const double* in_dev, int64_t count, int64_t stride, int64_t n,
+                       const double* base_dev, double scale, double* out_dev);
+/* Y (rows x cols, ldy) += a * X (rows x cols, ldx): K_ss + jitter * I - v^T v on the partitioned path
+ * (GP_regression.py:154), the all-reduced -v^T v added onto the covariance rows */
+int gpmi_dev_axpy2d(void* stream, double* Y_dev, int64_t ldy, const double* X_dev, int64_t ldx, int64_t rows,
+                    int64_t cols, double a);
 
 #ifdef __cplusplus
 }

@@ -14,14 +14,20 @@ def main():
     backend, device, out = sys.argv[4], sys.argv[5], sys.argv[6]
     N, d, n, nb = (int(v) for v in sys.argv[7:11])
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    # a wedged collective must not hang the suite: stacks of every thread and exit after the deadline, and a finite
+    # process-group timeout (the same watchdog ideas as bench.py)
+    import datetime
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("DISTGP_WORKER_DEADLINE_S", "540")), exit=True)
     import torch
     import torch.distributed as dist
     import gp_oracle as O
     from gaussian_process_amd.dist import DistGP
+    pg_timeout = datetime.timedelta(seconds=float(os.environ.get("DISTGP_WORKER_PG_TIMEOUT_S", "300")))
     if backend == "nccl":
-        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", rank), timeout=pg_timeout)
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     if device == "cpu":
         torch.set_num_threads(2)
         from numpy_block_ops import NumpyBlockOps

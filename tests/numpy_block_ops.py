@@ -175,5 +175,16 @@ class NumpyBlockOps:
         bb = self._a(b)
         bb[:] = sla.solve_triangular(np.tril(self._a(L)), bb, lower=True, trans='T', check_finite=False)
 
+    def sum_fixed(self, inp, count, stride, n, out, base=None, scale=1.0):
+        flat = self._a(inp).reshape(-1)
+        acc = np.zeros(n)
+        for q in range(int(count)):                 # index order, as the kernel adds them
+            acc = acc + flat[q * stride:q * stride + n]
+        self._a(out)[:n] = (self._a(base)[:n] + scale * acc) if base is not None else scale * acc
+
+    def axpy2d(self, Y, X, a):
+        y = self._a(Y)
+        y += a * self._a(X)
+
     def sync(self):
         pass

@@ -452,3 +452,41 @@ def test_bench_under_torch_distributed_run():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["value"] > 0
+
+
+def test_multi_rank_bench_cannot_hang_silently(tmp_path):
+    """bench.py's watchdog: a rank that stalls in front of a collective must end the run with a
+    non-zero code inside the deadline and with the stalled rank, step and phase on stderr.  The bench's skeleton on
+    gloo / CPU tensors (GPMI_BENCH_REHEARSE=gloo_cpu), rank 1 sleeping in step 1's alpha phase."""
+    import time
+    env = dict(os.environ, GPMI_BENCH_REHEARSE="gloo_cpu", GPMI_BENCH_STALL_RANK="1", GPMI_BENCH_STALL_STEP="1",
+               GPMI_BENCH_STALL_S="6", GPMI_BENCH_PG_TIMEOUT_S="12", GPMI_BENCH_DEADLINE_S="60", GPMI_BENCH_GRACE_S="8",
+               OMP_NUM_THREADS="1")
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    dt = time.monotonic() - t0
+    assert p.returncode != 0 and dt < 60, (p.returncode, dt)
+    assert "[bench watchdog] rank 1: no progress" in p.stderr and "since 'step 1 alpha'" in p.stderr, p.stderr[-2000:]
+    beats1 = [ln for ln in p.stderr.splitlines() if ln.startswith("[bench] rank 1 ")]
+    assert beats1[-1] == "[bench] rank 1 step 1 alpha"
+    assert "[bench parent] rank" in p.stderr
+    assert p.stdout.strip() == ""                        # no result line from a failed run
+    # the same run without a stalled rank ends cleanly with its one line
+    env.pop("GPMI_BENCH_STALL_RANK")
+    ok = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                        env=env, capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and '"rehearsal": "gloo_cpu"' in ok.stdout, ok.stderr[-2000:]
+
+
+def test_multi_rank_bench_parent_deadline(tmp_path):
+    """every rank wedged (no watchdog can help a process that never gets to run it: stall limit set far above the
+    deadline): the parent kills them at GPMI_BENCH_DEADLINE_S and exits 124"""
+    import time
+    env = dict(os.environ, GPMI_BENCH_REHEARSE="gloo_cpu", GPMI_BENCH_STALL_RANK="0", GPMI_BENCH_STALL_STEP="0",
+               GPMI_BENCH_STALL_S="600", GPMI_BENCH_PG_TIMEOUT_S="600", GPMI_BENCH_DEADLINE_S="10", OMP_NUM_THREADS="1")
+    t0 = time.monotonic()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 124 and time.monotonic() - t0 < 40, (p.returncode, p.stderr[-1500:])
+    assert "[bench parent] deadline of 10 s reached" in p.stderr

@@ -37,3 +37,22 @@ def test_c_abi_header_is_plain_c_and_cxx(tmp_path, lang, std):
     subprocess.check_call([GCC if lang == "c" else shutil.which("g++") or GCC, "-x", lang, "-std=" + std, "-Wall", "-Wextra",
                            "-Wpedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
                            str(tmp_path / "t.o")])
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_planners_under_asan_ubsan(tmp_path):
+    """The product's host-side launch planning (gaussian_process_amd/csrc/gpmi_plan.h: supertile / triangular / staircase
+    enumeration with its fixed prefix table, live-tile tests, block-width schedules, the bench line's flop counts) is the
+    same header the kernels are compiled from; here plain g++ builds it with AddressSanitizer + UBSan and
+    tests/sanitize/plan_check.cpp holds ~16 000 plans against brute force: every live tile enumerated exactly once, no
+    dead one, M up to 131072, every supertile edge, ragged sizes, a staircase one row too tall for its table."""
+    exe = str(tmp_path / "plan_check")
+    subprocess.check_call([shutil.which("g++"), "-O1", "-g", "-std=c++17", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=all", "-Wall", "-Wextra", "-Werror", "-I",
+                           os.path.join(ROOT, "gaussian_process_amd", "csrc"), "-o", exe,
+                           os.path.join(ROOT, "tests", "sanitize", "plan_check.cpp")])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-4000:]
+    assert "plan_check: ok" in p.stdout

@@ -56,7 +56,7 @@ class ThreadComm:
     def _meet(self):
         self.world.barrier.wait()
 
-    def broadcast(self, t, src):
+    def broadcast(self, t, src, tag=None):
         w = self.world
         self._drain(t)
         if self.rank == src:
@@ -67,7 +67,7 @@ class ThreadComm:
             self._drain(t)
         self._meet()
 
-    def all_gather(self, out, inp):
+    def all_gather(self, out, inp, tag=None):
         w = self.world
         self._drain(inp)
         w.slots[self.rank] = inp
@@ -79,14 +79,15 @@ class ThreadComm:
         self._drain(out)
         self._meet()
 
-    def all_reduce(self, t, op="sum"):
+    def all_reduce(self, t, op="sum", tag=None):
         w = self.world
         self._drain(t)
         w.slots[self.rank] = t.clone()
         self._meet()
         acc = w.slots[0].clone()
         for r in range(1, self.size):
-            acc = torch.minimum(acc, w.slots[r]) if op == "min" else acc + w.slots[r]
+            acc = torch.minimum(acc, w.slots[r]) if op == "min" else torch.maximum(acc, w.slots[r]) if op == "max" \
+                else acc + w.slots[r]
         t.copy_(acc)
         self._drain(t)
         self._meet()
