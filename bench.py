@@ -389,6 +389,7 @@ def run_replay(args):
         nb_auto *= 2
     nb = int(os.environ.get("GPMI_DIST_NB", str(nb_auto)))
     lookahead = int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2"))
+    layout = os.environ.get("GPMI_DIST_LAYOUT", "snake")
     # T(1 GPU): the product's single-GPU path, same step as the bench line
     wd.beat("single-GPU reference")
     t1_ms = None
@@ -410,7 +411,7 @@ def run_replay(args):
     res = []
     for r in ranks:
         wd.beat("replay rank %d of %d" % (r, G))
-        gp = replay_rank(0, src, r, G, X, y, Xs, lookahead=lookahead)
+        gp = replay_rank(0, src, r, G, X, y, Xs, lookahead=lookahead, layout=layout)
 
         def step():
             lml = gp.factorize(sigma, ell, s)
@@ -454,7 +455,7 @@ def run_replay(args):
     return {"replay": True, "what": "one rank of a G-rank DistGP run alone on one GPU: its row blocks, panel solves, update launches, "
             "streams, events, pack copies and Python issue are a real rank's; collectives are device copies out of a stored "
             "factorisation (gaussian_process_amd/replay.py), so xGMI time is NOT in these numbers",
-            "of": G, "ranks": res, "block_rows": nb, "lookahead": lookahead,
+            "of": G, "ranks": res, "block_rows": nb, "lookahead": lookahead, "layout": layout,
             "config": {"workload": "GP fit+predict N=%d d=%d n_test=%d" % (N, d, n), "N": N, "d": d, "n_test": n},
             "t1_ms": t1_ms, "t1_what": "single-GPU path (GPContext), same step, this run",
             "worst_rank_ms": worst,
@@ -660,6 +661,7 @@ def main():
             out["rccl_ranks"] = dist.get_world_size()
             out["backend"] = backend
             out["config"]["block_rows"] = nb_used
+            out["config"]["row_block_layout"] = gp.layout
             out["stages_ms"] = stage            # last step, rank 0: fit / alpha / predict wall
             out["per_rank_ms"] = per_rank
             out["per_rank_diag"] = diag_all

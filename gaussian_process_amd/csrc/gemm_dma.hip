@@ -62,6 +62,7 @@ struct GemmDmaDev {
     // persistent form: work counters of this launch (one per XCD) and the number of virtual blocks
     struct PersistSlot* slot;
     int nblocks;
+    int stagger;                  // per-tile form, experiment (option gemm_stagger): phases the first round's workgroups are spread over
 };
 
 // Work counters of one persistent launch: workgroups on XCD x draw block numbers 8 w + x from ctr[x]; the last
@@ -103,7 +104,8 @@ constexpr unsigned TICKET_NONE = 0xFFFFFFFFu;
 // next block number for a workgroup whose blocks run on XCD group `xcd`: from its own group's counter while that lasts
 // (the supertile -> L2 map of the per-tile launch), then from the other groups' (the tail of a launch: an XCD that
 // runs out early takes work from the slower ones instead of idling -- the hardware's static block -> XCD deal cannot)
-__device__ __forceinline__ unsigned ticket_draw(const GemmDmaDev& p, int xcd) {
+template <class PT>
+__device__ __forceinline__ unsigned ticket_draw(const PT& p, int xcd) {
     const unsigned per = (unsigned)p.nblocks >> 3;
 #pragma unroll 1
     for (int t = 0; t < 8; ++t) {
@@ -146,6 +148,14 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
     } else {
         live = dma_map_tile(p, ti, tj) && dma_tile_live(p, ti, tj);
         if (!live) return;
+        // experiment: the tiles of a launch start and end in step, so a kernel of the other stream that needs a whole CU
+        // waits for the next ROUND boundary (half a tile time on average).  Holding part of the first round back by a
+        // fraction of a tile time spreads the boundaries: stagger phases, (tile time) / stagger apart.
+        if (p.stagger > 1 && blockIdx.x < 320) {
+            const int ph = (int)((blockIdx.x >> 3) % (unsigned)p.stagger);
+            const int naps = ph * p.nchunks / (2 * p.stagger);        // ~8k cycles each; a K step of 16 takes ~4.2k
+            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+        }
     }
    if (live) {
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
@@ -471,11 +481,11 @@ __device__ __forceinline__ void gemm_nt_dma_persist_body(const GemmDmaDev& p) {
     // A tile as the loop wants it: the four DMA source pointers of this lane (its 8-row pieces of the A rows and of
     // the B rows of the tile, K step 0) and the wave-uniform base of this wave's part of the C tile
     struct TileRef { const double* d[DPW]; GPMI_GLB char* c; };
-    // block number w of this XCD -> tile; false: nothing to do for it
-    auto resolve = [&](unsigned w, TileRef& t) -> bool {
+    // block number -> tile; false: nothing to do for it
+    auto resolve = [&](unsigned b, TileRef& t) -> bool {
         const GPMI_CONST GemmDmaDev* pp = kernarg();
         int ti, tj;
-        if (!dma_block_to_tile(*pp, (int)(w * 8u + (unsigned)xcd), ti, tj)) return false;
+        if (!dma_block_to_tile(*pp, (int)b, ti, tj)) return false;
         if (!dma_tile_live(*pp, ti, tj)) return false;
         // wave-uniform, but the map goes through a float square root (vector unit): back to scalar registers
         ti = __builtin_amdgcn_readfirstlane(ti);
@@ -493,14 +503,13 @@ __device__ __forceinline__ void gemm_nt_dma_persist_body(const GemmDmaDev& p) {
         t.c = (GPMI_GLB char*)uniform_ptr(tc);
         return true;
     };
-    auto draw = [&]() -> unsigned {                 // one lane of the workgroup
+    // the next block number of this workgroup (one lane): from its own XCD group's counter while that lasts, then from
+    // the other groups' (ticket_draw: the tail of a launch is shared by all CUs) -- TICKET_NONE when every counter is used up
+    auto draw = [&]() -> unsigned {
         const GPMI_CONST GemmDmaDev* pp = kernarg();
-        return atomicAdd(&pp->slot->ctr[xcd], 1u);
+        return ticket_draw(*pp, xcd);
     };
-    auto past_end = [&](unsigned w) -> bool {
-        const GPMI_CONST GemmDmaDev* pp = kernarg();
-        return w >= ((unsigned)pp->nblocks >> 3);
-    };
+    auto past_end = [&](unsigned b) -> bool { return b == TICKET_NONE; };
     // a wave-uniform flag the compiler computed with vector compares -> a scalar one (scalar branches in the loop)
     auto scalar_flag = [](bool f) -> bool { return __builtin_amdgcn_readfirstlane(f ? 1 : 0) != 0; };
     // synchronous draw (start of the kernel, after a drain): false when the XCD's blocks are used up
@@ -733,6 +742,7 @@ struct GemmSmallDev {
     int Tm, Tn, nchunks;
     int lower;
     int64_t diag_off;
+    int prio;
 };
 
 template <int SM_STAGES>
@@ -743,6 +753,7 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmSmallDev p
         const int64_t min_col = (int64_t)tj * SM_T, max_row = (int64_t)ti * SM_T + SM_T - 1;
         if (min_col > max_row + p.diag_off) return;
     }
+    if (p.prio) __builtin_amdgcn_s_setprio(3);     // option panel_prio (beside a trailing update only)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -840,6 +851,7 @@ hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a) {
     p.C = a.C; p.A = a.A; p.B = a.B; p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
     p.Tm = (int)(a.M / SM_T); p.Tn = (int)(a.N / SM_T); p.nchunks = (int)(a.K / 16);
     p.lower = a.lower; p.diag_off = a.diag_off;
+    p.prio = (t_small_shallow && tuning().panel_prio) ? 1 : 0;
     constexpr size_t lds8 = (size_t)8 * SM_STAGE_SLOTS * 16, lds3 = (size_t)3 * SM_STAGE_SLOTS * 16;
     static PerDeviceOnce once;
     const hipError_t ea = once.run([&]() -> hipError_t {
@@ -928,6 +940,7 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     p.stamps = tn.gemm_stamps;
     p.slot = nullptr;
     p.nblocks = nblocks;
+    p.stagger = (tn.gemm_stagger > 1 && a.role == 1 && gemm_two_streams_active() && nblocks >= 512) ? tn.gemm_stagger : 0;
     // persistent form: launches with at least two rounds of tiles and a K loop long enough to draw the successor in --
     // and the chip to themselves: resident workgroups (216 registers per lane, two waves per SIMD) leave no room on a
     // CU for the panel kernels of the other stream, which would then wait for the whole launch instead of a tile

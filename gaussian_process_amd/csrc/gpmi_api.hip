@@ -20,9 +20,10 @@ using namespace gpmi;
 namespace gpmi {
 thread_local std::string g_err;
 
-static const Tuning k_default_tuning;
+// options of the context-free gpmi_dev_* primitives called from this thread (gpmi_dev_set_option); the defaults otherwise
+static thread_local Tuning t_dev_tuning;
 static thread_local const Tuning* t_tuning = nullptr;
-const Tuning& tuning() { return t_tuning ? *t_tuning : k_default_tuning; }
+const Tuning& tuning() { return t_tuning ? *t_tuning : t_dev_tuning; }
 TuneScope::TuneScope(const Tuning* t) : prev(t_tuning) { t_tuning = t; }
 TuneScope::~TuneScope() { t_tuning = prev; }
 }
@@ -80,6 +81,46 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
     return GPMI_OK;
 }
 
+// kernel-selection options (gpmi_internal.h: Tuning) by name; -1: no such option, else a status
+static int set_tuning_option(Tuning& t, const char* name, int64_t value) {
+    if (!strcmp(name, "gemm_small_tiles")) {
+        t.gemm_small_tiles = value ? 1 : 0;
+    } else if (!strcmp(name, "trsm_wave")) {
+        t.trsm_wave = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_small_dma")) {
+        t.gemm_small_dma = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_persist")) {
+        t.gemm_persist = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_ticket")) {
+        if (value < 0 || value > 2) return fail_arg("gemm_ticket must be 0 (off), 1 (trailing updates under lookahead) or 2 (every launch)");
+        t.gemm_ticket = (int)value;
+    } else if (!strcmp(name, "panel_prio")) {
+        t.panel_prio = value ? 1 : 0;
+    } else if (!strcmp(name, "gemm_stagger")) {
+        if (value < 0 || value > 8) return fail_arg("gemm_stagger must be in 0..8");
+        t.gemm_stagger = (int)value;
+    } else if (!strcmp(name, "gemm_reserve")) {
+        if (value < 0 || value > 24) return fail_arg("gemm_reserve must be in 0..24 (CUs per XCD)");
+        t.gemm_reserve = (int)value;
+    } else if (!strcmp(name, "trsv_vinv")) {
+        if (value < 0 || value > 2) return fail_arg("trsv_vinv must be 0 (16 x 16 rounds), 1 (one launch per block) or 2 (one launch)");
+        t.trsv_vinv = (int)value;
+    } else if (!strcmp(name, "panel_fused")) {
+        t.panel_fused = value ? 1 : 0;
+    } else if (!strcmp(name, "rbf_blocks")) {
+        if (value < 1 || value > (1 << 24)) return fail_arg("rbf_blocks must be in 1..2^24");
+        t.rbf_blocks = (int)value;
+    } else if (!strcmp(name, "gemm_dma_waves")) {
+        if (value != 4 && value != 8) return fail_arg("gemm_dma_waves must be 4 or 8");
+        t.gemm_dma_waves = (int)value;
+    } else if (!strcmp(name, "gemm_dma")) {
+        t.gemm_use_dma = value ? 1 : 0;
+    } else {
+        return -1;
+    }
+    return GPMI_OK;
+}
+
 int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
     if (!c || !name) return fail_arg("gpmi_set_option: null argument");
     if (!strcmp(name, "nb")) {
@@ -104,37 +145,21 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         // blocks count as "last" (0: three)
         if (value < 0 || (value & 8) || (value >> 4) > 64) return fail_arg("ramp: bits 0-2 and a tail count of at most 64 in bits 4..");
         c->ramp = (int)value;
-    } else if (!strcmp(name, "gemm_small_tiles")) {
-        c->tune.gemm_small_tiles = value ? 1 : 0;
-    } else if (!strcmp(name, "trsm_wave")) {
-        c->tune.trsm_wave = value ? 1 : 0;
-    } else if (!strcmp(name, "gemm_small_dma")) {
-        c->tune.gemm_small_dma = value ? 1 : 0;
-    } else if (!strcmp(name, "gemm_persist")) {
-        c->tune.gemm_persist = value ? 1 : 0;
-    } else if (!strcmp(name, "gemm_ticket")) {
-        if (value < 0 || value > 2) return fail_arg("gemm_ticket must be 0 (off), 1 (trailing updates under lookahead) or 2 (every launch)");
-        c->tune.gemm_ticket = (int)value;
-    } else if (!strcmp(name, "gemm_reserve")) {
-        if (value < 0 || value > 24) return fail_arg("gemm_reserve must be in 0..24 (CUs per XCD)");
-        c->tune.gemm_reserve = (int)value;
-    } else if (!strcmp(name, "trsv_vinv")) {
-        if (value < 0 || value > 2) return fail_arg("trsv_vinv must be 0 (16 x 16 rounds), 1 (one launch per block) or 2 (one launch)");
-        c->tune.trsv_vinv = (int)value;
-    } else if (!strcmp(name, "panel_fused")) {
-        c->tune.panel_fused = value ? 1 : 0;
-    } else if (!strcmp(name, "rbf_blocks")) {
-        if (value < 1 || value > (1 << 24)) return fail_arg("rbf_blocks must be in 1..2^24");
-        c->tune.rbf_blocks = (int)value;
-    } else if (!strcmp(name, "gemm_dma_waves")) {
-        if (value != 4 && value != 8) return fail_arg("gemm_dma_waves must be 4 or 8");
-        c->tune.gemm_dma_waves = (int)value;
-    } else if (!strcmp(name, "gemm_dma")) {
-        c->tune.gemm_use_dma = value ? 1 : 0;
     } else {
-        return fail_arg("gpmi_set_option: unknown option");
+        const int rc = set_tuning_option(c->tune, name, value);
+        if (rc < 0) return fail_arg("gpmi_set_option: unknown option");
+        return rc;
     }
     return GPMI_OK;
+}
+
+// The same kernel-selection options for the context-free gpmi_dev_* block primitives called from THIS thread (the
+// multi-rank driver): e.g. "gemm_ticket" 2 around its large update launches.  Thread-local; the defaults otherwise.
+int gpmi_dev_set_option(const char* name, int64_t value) {
+    if (!name) return fail_arg("gpmi_dev_set_option: null argument");
+    const int rc = set_tuning_option(t_dev_tuning, name, value);
+    if (rc < 0) return fail_arg("gpmi_dev_set_option: unknown option");
+    return rc;
 }
 
 int gpmi_set_kernel(gpmi_ctx* c, int kind, double p0, double p1) {

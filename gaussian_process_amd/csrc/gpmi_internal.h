@@ -20,6 +20,8 @@ struct Tuning {
     int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
     int gemm_persist = 1;       // resident workgroups that chain the K loops of consecutive tiles (launches with >= 2 rounds of tiles)
     int gemm_ticket = 0;        // ticket form of the per-tile kernel (resident workgroups, tiles drawn from counters, no state across tiles): 1 Cholesky trailing updates under lookahead, 2 every launch of at least one round
+    int panel_prio = 0;         // 1: trsm128 and the small GEMM raise their waves' issue priority (s_setprio 3) -- for the forms that share CUs with a trailing update
+    int gemm_stagger = 0;       // experiment: spread the first round of a trailing update under lookahead over this many phases (0 / 1: off)
     int gemm_reserve = 0;       // ticket form: CUs per XCD the launch leaves untouched (for the panel kernels of the other stream)
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always
@@ -192,8 +194,9 @@ hipError_t launch_vinv128(hipStream_t s, double* A, int64_t ld, int64_t n, doubl
 hipError_t launch_trsv_lt_vinv(hipStream_t s, const double* L, int64_t ld, double* b, double* xout, int64_t n);
 // the same in ONE launch (column blocks chained through the solution vector itself); m is only read; err_dev: one int,
 // set if a poll gave up
+// skip / max_wait_ms: gpmi_probe_trsv_giveup only (bottom blocks left unsolved, a shorter bound on every wait; 0: 10 s)
 hipError_t launch_trsv_lt_chain(hipStream_t s, const double* L, int64_t ld, const double* vside, const double* m,
-                                double* xout, int64_t n, int* err_dev);
+                                double* xout, int64_t n, int* err_dev, int skip = 0, double max_wait_ms = 0.0);
 // y[c] = sum_r A[r][c] * x[r]; scratch: ceil(nrows/64) * ncols doubles
 hipError_t launch_gemv_t(hipStream_t s, const double* A, int64_t ld, int64_t nrows, int64_t ncols,
                          const double* x, double* y, double* scratch);

@@ -226,6 +226,48 @@ int gpmi_probe_panel(gpmi_ctx* c, int kind, int64_t m, int reps, double* out_us,
     return GPMI_OK;
 }
 
+// The give-up path of the one-launch backward solve (solve.hip: trsv_lt_chain_kernel): on a trivially solvable system
+// (L = I, n unknowns) the bottom block is deliberately left unsolved, so every wait runs into its bound (wait_ms instead
+// of the product's 10 s).  *err_out = the kernel's error word (1 expected), *elapsed_ms = how long the launch took:
+// every wave must LEAVE the kernel, with NaN in place of the entries it waited for.
+int gpmi_probe_trsv_giveup(gpmi_ctx* c, int64_t n, double wait_ms, int* err_out, double* elapsed_ms, double* x_out) {
+    if (!c || !err_out || !elapsed_ms || !x_out) return fail_arg("gpmi_probe_trsv_giveup: null argument");
+    if (n < 256 || n % TILE || n > 8192 || !(wait_ms > 0.0) || wait_ms > 5000.0) return fail_arg("gpmi_probe_trsv_giveup: n in 256..8192 (multiple of 128), wait_ms in (0, 5000]");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    DevBuf L, vs, m, x, err;
+    HIP_TRY(L.ensure((size_t)n * n * 8));
+    HIP_TRY(vs.ensure((size_t)n * 128 * 8));
+    HIP_TRY(m.ensure((size_t)n * 8));
+    HIP_TRY(x.ensure((size_t)n * 8));
+    HIP_TRY(err.ensure(64));
+    HIP_TRY(hipMemsetAsync(L.p, 0, (size_t)n * n * 8, s));
+    HIP_TRY(hipMemsetAsync(vs.p, 0, (size_t)n * 128 * 8, s));
+    HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
+    HIP_TRY(launch_set_identity_diag(s, L.as<double>(), n, n));
+    std::vector<double> hv((size_t)n * 128, 0.0), hm((size_t)n, 1.0);
+    for (int64_t r = 0; r < n; ++r) hv[(size_t)r * 128 + (size_t)(r % 128)] = 1.0;      // V_kk = I for every block
+    HIP_TRY(hipMemcpyAsync(vs.p, hv.data(), hv.size() * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(m.p, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
+    hipEvent_t a = nullptr, b = nullptr;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s);
+    hipError_t e = launch_trsv_lt_chain(s, L.as<double>(), n, vs.as<double>(), m.as<double>(), x.as<double>(), n, err.as<int>(),
+                                        1, wait_ms);
+    (void)hipEventRecord(b, s);
+    hipError_t e2 = hipStreamSynchronize(s);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (e != hipSuccess) return fail_runtime(e, "trsv_lt_chain launch");
+    if (e2 != hipSuccess) return fail_runtime(e2, "trsv_lt_chain sync");
+    HIP_TRY(hipMemcpy(err_out, err.p, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(x_out, x.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+    *elapsed_ms = ms;
+    L.release(); vs.release(); m.release(); x.release(); err.release();
+    return GPMI_OK;
+}
+
 // One resident workgroup that does nothing: `threads` threads and `lds_bytes` of LDS it never touches, asleep for
 // `milliseconds` on a stream of its own (high_priority != 0: the device's highest stream priority).  Returns at once; time
 // something else (gpmi_probe_gemm) while it is resident to see what a workgroup that merely HOLDS a CU costs the rest of the

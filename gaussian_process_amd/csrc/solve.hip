@@ -405,7 +405,7 @@ constexpr unsigned long long TRSV_SENTINEL = 0xFFFFFFFFFFFFFFFFull;
 // 100 MHz on gfx950: 10 s.
 constexpr unsigned long long TRSV_MAX_WAIT_TICKS = 1000000000ull;
 
-__device__ __forceinline__ double trsv_poll(const double* p, int* err) {
+__device__ __forceinline__ double trsv_poll(const double* p, int* err, unsigned long long max_ticks) {
     const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
     unsigned long long v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v != TRSV_SENTINEL) return __longlong_as_double((long long)v);
@@ -414,7 +414,7 @@ __device__ __forceinline__ double trsv_poll(const double* p, int* err) {
     while (v == TRSV_SENTINEL) {
         __builtin_amdgcn_s_sleep(1);
         v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((++polls & 1023) == 0 && wall_clock64() - t0 > TRSV_MAX_WAIT_TICKS) { *err = 1; v = 0x7FF8000000000000ull; break; }
+        if ((++polls & 1023) == 0 && wall_clock64() - t0 > max_ticks) { *err = 1; v = 0x7FF8000000000000ull; break; }
     }
     return __longlong_as_double((long long)v);
 }
@@ -429,13 +429,15 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
 __global__ __launch_bounds__(256, 2) void trsv_lt_chain_kernel(const double* __restrict__ L, int64_t ld,
                                                                 const double* __restrict__ vside,
                                                                 const double* __restrict__ m, double* x, int T,
-                                                                int* err) {
+                                                                int* err, int skip, unsigned long long max_ticks) {
     __shared__ __attribute__((aligned(16))) double v0s[64 * 64];     // V_kk[0:64, 0:64]
     __shared__ double red[4][128];
     __shared__ __attribute__((aligned(16))) double rs[128];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k = T - 1 - (int)blockIdx.x;
+    // skip != 0 (gpmi_probe_trsv_giveup only): the bottom `skip` blocks are never solved, so every workgroup's first
+    // wait runs into its bound -- the only way to exercise the give-up path, which no finite or non-finite factor reaches
+    const int k = T - 1 - skip - (int)blockIdx.x;
     const int64_t k0 = (int64_t)k * 128;
     const int n = 2 * (T - 1 - k);           // 64-row chunks of L below my diagonal block, walked bottom-up
     // chunk i < n: rows 64 (2 T - 1 - i) .. + 63 of L (block j = T - 1 - i / 2: its upper half for odd i);
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(256, 2) void trsv_lt_chain_kernel(const double* __r
             xv = rs[64 + 16 * w + (lane & 15)];                                                      \
         } else if (!((i) & 1)) {                                                                     \
             const int64_t j0_ = (int64_t)(T - 1 - (i) / 2) * 128;                                    \
-            xv = trsv_poll(x + j0_ + ((lane & 16) ? 0 : 64) + 16 * w + (lane & 15), &lerr);          \
+            xv = trsv_poll(x + j0_ + ((lane & 16) ? 0 : 64) + 16 * w + (lane & 15), &lerr, max_ticks); \
         }                                                                                            \
         TRSV_LOAD(nxt2, (i) + 2)                                                                     \
         TRSV_FMA(cur, xv, 16 * ((i) & 1))                                                            \
@@ -535,14 +537,16 @@ __global__ __launch_bounds__(256, 2) void trsv_lt_chain_kernel(const double* __r
 // filled with the "not yet" pattern.  err_dev: one int the kernel sets if a poll gave up (it never does on a finite
 // factor).
 hipError_t launch_trsv_lt_chain(hipStream_t s, const double* L, int64_t ld, const double* vside, const double* m,
-                                double* xout, int64_t n, int* err_dev) {
+                                double* xout, int64_t n, int* err_dev, int skip, double max_wait_ms) {
     if (n <= 0 || n % 128 || ld % 2 || n / 128 > (1 << 20) || !err_dev || !vside) return hipErrorInvalidValue;
     // the kernel reads L, vside and its LDS staging with 16-byte loads: a view with an odd column offset is refused
     if ((reinterpret_cast<uintptr_t>(L) & 15) || (reinterpret_cast<uintptr_t>(vside) & 15)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(xout, 0xFF, (size_t)n * 8, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(trsv_lt_chain_kernel, dim3((unsigned)(n / 128)), dim3(256), 0, s, L, ld, vside, m, xout, (int)(n / 128),
-                       err_dev);
+    if (skip < 0 || skip >= n / 128) return hipErrorInvalidValue;
+    const unsigned long long ticks = max_wait_ms > 0 ? (unsigned long long)(max_wait_ms * 1e5) : TRSV_MAX_WAIT_TICKS;   // 100 MHz
+    hipLaunchKernelGGL(trsv_lt_chain_kernel, dim3((unsigned)(n / 128 - skip)), dim3(256), 0, s, L, ld, vside, m, xout,
+                       (int)(n / 128), err_dev, skip, ticks);
     return hipGetLastError();
 }
 

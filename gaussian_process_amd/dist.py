@@ -5,9 +5,10 @@ torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
 Reference path: GP_regression.py:126-148 / tune_hyperparms_regression.py:306-312 (the
 reference itself is single-process NumPy; SURVEY.md section 8e is the design this follows).
 
-Layout.  NB-row blocks of K + sI; global block b lives on rank b % G, stacked in
-increasing b in that rank's local matrix A (rows) x (Np + pad) -- row-major, so the
-rank holds whole rows of L.  One extra 128-row block carries y (rank T % G): the
+Layout.  NB-row blocks of K + sI; global block b lives on rank owner[b] (block_layout: the blocks
+dealt boustrophedon by default -- "snake" -- which balances the ranks' shares of the update; plain
+b % G with layout="cyclic"), stacked in increasing b in that rank's local matrix A (rows) x (Np + pad)
+-- row-major, so the rank holds whole rows of L.  One extra 128-row block carries y (owner[T]): the
 factorisation sweeps it like any other row block, so it ends as m = L^-1 y.
 
 Right-looking step k (block column k):
@@ -48,6 +49,32 @@ INT64_MAX = (1 << 63) - 1
 
 def _round_up(x, m):
     return (x + m - 1) // m * m
+
+
+def block_layout(T, G, layout):
+    """Which rank owns row block b (b = 0 .. T; block T is the y block), for the two row-block distributions:
+      "cyclic"  b -> b % G.
+      "snake"   the same dealt boustrophedon: blocks 0 .. G-1 to ranks 0 .. G-1, blocks G .. 2G-1 to ranks G-1 .. 0, and so on.
+    Over the factorisation row block b is updated by b (b + 1) / 2 block products (step k < b touches its columns k + 1 .. b),
+    so a rank's share of the work is the sum of that over its blocks, and cyclic dealing gives the last rank much more of it
+    than the first: N = 65536, nb = 1024, 8 ranks -- rank 7 (blocks 7, 15, .. 63) carries 6384 units, rank 0 4592, the mean
+    is 5460, and the step ends when rank 7 does (replay: 277 ms against 225).  The snake's worst rank carries 5600 there
+    (+2.6 % over the mean instead of +16.9 %).  Either way at most one block per rank separates the ranks' row counts at
+    any step, so the per-step balance of the panel solves is the cyclic one.
+    Returns (owner[b] for b <= T, local index li[b], blocks[r] = that rank's blocks < T in increasing order)."""
+    if layout not in ("cyclic", "snake"):
+        raise ValueError("layout must be 'cyclic' or 'snake'")
+    own = []
+    for b in range(T + 1):
+        q, i = divmod(b, G)
+        own.append(G - 1 - i if (layout == "snake" and q % 2) else i)
+    blocks = [[b for b in range(T) if own[b] == r] for r in range(G)]
+    li = [0] * (T + 1)
+    for r in range(G):
+        for j, b in enumerate(blocks[r]):
+            li[b] = j
+    li[T] = len(blocks[own[T]])
+    return own, li, blocks
 
 
 class TorchComm:
@@ -222,6 +249,10 @@ class HipBlockOps:
     def set_concurrent(self, on):
         check(self.lib.gpmi_dev_set_concurrent(1 if on else 0))
 
+    def set_option(self, name, value):
+        """kernel-selection option of the block primitives called from this thread (gpmi_dev_set_option)"""
+        check(self.lib.gpmi_dev_set_option(name.encode(), int(value)))
+
     def sync(self):
         torch.cuda.synchronize(self.device)
 
@@ -252,9 +283,14 @@ class DistGP:
     """Row-block cyclic GP fit / predict over the ranks of `group` (default: WORLD)."""
 
     def __init__(self, device_index=0, nb=512, ld_pad=32, ops=None, group=None, lookahead=2,
-                 force_collectives=False, comm=None):
+                 force_collectives=False, comm=None, layout=None):
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
+        import os
+        # how the row blocks are dealt to the ranks (block_layout): "snake" balances the ranks' shares of the update
+        self.layout = layout if layout is not None else os.environ.get("GPMI_DIST_LAYOUT", "snake")
+        if self.layout not in ("cyclic", "snake"):
+            raise ValueError("layout must be 'cyclic' or 'snake'")
         self.comm = comm if comm is not None else TorchComm(group)
         self.group = group
         self.rank = self.comm.rank
@@ -272,6 +308,10 @@ class DistGP:
         # solves and updates its own block row and factors the block on a third stream before the
         # rest of panel k is gathered, so the latency-bound potrf leaves the collective chain
         self.lookahead = int(lookahead)
+        # large update launches in the ticket form of the GEMM (resident workgroups that draw tiles from per-XCD counters and
+        # take over the other XCDs' tails -- a rank's staircase of row blocks is dealt unevenly to the XCDs): on wherever no
+        # kernel of another stream needs a whole CU meanwhile, i.e. not while this rank factors a diagonal block
+        self.ticket = int(os.environ.get("GPMI_DIST_TICKET", "1"))
         self.have_factor = False
         self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
         self._vside = {}             # local diagonal block -> its inverses' side buffer (one-launch backward solve)
@@ -313,11 +353,12 @@ class DistGP:
 
     def _lstart(self, k, r=None):
         """first local block index of rank r whose global block index is > k"""
+        import bisect
         r = self.rank if r is None else r
-        return 0 if k < r else (k - r) // self.G + 1
+        return bisect.bisect_right(self._blocks[r], k)
 
     def _nblocks(self, r):
-        return len(range(r, self.T, self.G))
+        return len(self._blocks[r])
 
     def _tensor(self, *shape, dtype=torch.float64):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
@@ -390,9 +431,10 @@ class DistGP:
         NB, G = self.NB, self.G
         self.Np = _round_up(self.N, NB)
         self.T = self.Np // NB
-        self.my_blocks = list(range(self.rank, self.T, G))
+        self._own, self._li, self._blocks = block_layout(self.T, G, self.layout)
+        self.my_blocks = list(self._blocks[self.rank])
         self.nloc = len(self.my_blocks)
-        self.ry = self.T % G                         # rank that carries the y block
+        self.ry = self._own[self.T]                  # rank that carries the y block
         self.yrow = self.nloc * NB if self.rank == self.ry else None
         self.rows = self.nloc * NB + (YB if self.rank == self.ry else 0)
         self.ld = self.Np + self.ld_pad
@@ -420,9 +462,8 @@ class DistGP:
             ck = max(cnts)
             starts.append(len(offs))
             for b in range(k + 1, self.T):
-                r = b % G
-                first = r + self._lstart(k, r) * G
-                offs.append((r * ck + (b - first) // G) * NB * NB)
+                r = self._own[b]
+                offs.append((r * ck + self._li[b] - self._lstart(k, r)) * NB * NB)
         self.boff_h = np.ascontiguousarray(offs or [0], dtype=np.int64)
         self.boff = torch.from_numpy(self.boff_h).to(self.dev)
         self.boff_start = starts
@@ -476,6 +517,23 @@ class DistGP:
         self.rowmapC_h = np.ascontiguousarray(flatC or [0], dtype=np.int32)
         self.have_factor = False
         self.have_test = False
+
+    def _ticket(self, on):
+        """context manager: the enclosed update launches use the ticket form of the GEMM (HIP primitives only)"""
+        import contextlib
+        ops = self.ops
+
+        @contextlib.contextmanager
+        def scope():
+            if on and self.ticket and hasattr(ops, "set_option"):
+                ops.set_option("gemm_ticket", 2)
+                try:
+                    yield
+                finally:
+                    ops.set_option("gemm_ticket", 0)
+            else:
+                yield
+        return scope()
 
     def _concurrent(self, on):
         """context manager: the block primitives' beside-an-update forms (gpmi_dev_set_concurrent) for the enclosed sweep"""
@@ -607,10 +665,10 @@ class DistGP:
         """Block column k: owner factors the diagonal block, broadcast, every rank solves its
         rows below, all-gather of the panel column into buf."""
         ops, NB, G, A = self.ops, self.NB, self.G, self.A
-        owner = k % G
+        owner = self._own[k]
         c0 = k * NB
         if self.rank == owner:
-            li = k // G
+            li = self._li[k]
             diag = A[li * NB:(li + 1) * NB, c0:c0 + NB]
             with self._timed("diag", None):
                 ops.potrf_block(diag, c0, self.info)
@@ -644,14 +702,14 @@ class DistGP:
         ev_a = self._record("main")                      # the K build
         self._wait("crit", ev_a)
         with self._on("crit"):
-            if self.rank == 0 % G:
+            if self.rank == self._own[0]:
                 diag = A[0:NB, 0:NB]
                 with self._timed("diag", None):
                     ops.potrf_block(diag, 0, self.info)
                     Lk[0].copy_(diag)
             if self.coll:
                 with self._timed("bcast", None):
-                    self.comm.broadcast(Lk[0], 0, tag=("Lkk", 0))
+                    self.comm.broadcast(Lk[0], self._own[0], tag=("Lkk", 0))
         ev_bcast = self._record("crit")
         ev_panel_prev = None                             # side-stream work of step k-1 (last reader of Lk[(k+1) % 2])
         import time
@@ -661,7 +719,7 @@ class DistGP:
             buf = self.Pbuf[k % 2]
             c0, c1 = k * NB, (k + 1) * NB
             ls = self._lstart(k)                         # my first local block below k
-            own_next = (k + 1 < T) and (self.rank == (k + 1) % G)
+            own_next = (k + 1 < T) and (self.rank == self._own[k + 1])
             ev_row = None
             # Lk[(k+1) % 2] is overwritten below (owner: copy of its new diagonal block; everyone: the
             # broadcast); its last reader is the side stream's solve of step k-1
@@ -697,7 +755,7 @@ class DistGP:
             with self._on("crit"):                       # queued behind the owner's potrf on this stream
                 if self.coll:
                     with self._timed("bcast", None):
-                        self.comm.broadcast(Lk[(k + 1) % 2], (k + 1) % G, tag=("Lkk", k + 1))
+                        self.comm.broadcast(Lk[(k + 1) % 2], self._own[k + 1], tag=("Lkk", k + 1))
             ev_bcast = self._record("crit")
             with self._timed("stall_panel", "main"):      # elapsed between these two events = main-stream time lost to the panel chain
                 self._wait("main", ev_panel)
@@ -717,8 +775,11 @@ class DistGP:
             ev_a = self._record("main")
             if k + 2 < T and m1 > 0:                     # (b) the remaining columns
                 off, ln = self.rowmapB_off[k], self.rowmapB_len[k]
-                self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
-                             self.rowmapC[off:off + ln], self.rowmapC_h[off:off + ln])
+                # ticket form unless this rank factors diagonal block k+1 meanwhile (potrf128 needs a whole CU, and
+                # resident workgroups would keep every CU until the launch ends)
+                with self._ticket(not own_next):
+                    self._update(k, buf, A[r1:r1 + m1, c1 + NB:self.Np], A[r1:r1 + m1, c0:c0 + NB], 1,
+                                 self.rowmapC[off:off + ln], self.rowmapC_h[off:off + ln])
             if self._prof is not None:
                 self._prof.setdefault("host_issue", []).append((t_issue, time.perf_counter()))
         self._wait("main", ev_bcast)
@@ -862,8 +923,8 @@ class DistGP:
 
             def solve_block(k, Xk):
                 """owner: v^T block k <- block * L_kk^-T; everyone receives it in Xk"""
-                if self.rank == k % G:
-                    li = k // G
+                if self.rank == self._own[k]:
+                    li = self._li[k]
                     blk = V[:, li * NB:(li + 1) * NB]
                     with self._timed("solve_v", None):
                         ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
@@ -871,7 +932,7 @@ class DistGP:
                             Xk.copy_(blk)
                 if self.coll and k < T - 1:
                     with self._timed("bcast_v", None):
-                        self.comm.broadcast(Xk, k % G, tag=("vblock", k))
+                        self.comm.broadcast(Xk, self._own[k], tag=("vblock", k))
 
             def xk_view(k):
                 return self.Xk[k % 2] if self.coll else V[:, k * NB:(k + 1) * NB]
@@ -896,9 +957,9 @@ class DistGP:
                     Xk = xk_view(k)
                     c0 = k * NB
                     ls = self._lstart(k)
-                    own_next = (self.rank == (k + 1) % G)
+                    own_next = (self.rank == self._own[k + 1])
                     if own_next:                               # (a) my block k+1 first
-                        li = (k + 1) // G
+                        li = self._li[k + 1]
                         with self._timed("update_v", None):
                             ops.gemm_nt(V[:, li * NB:(li + 1) * NB], Xk, A[li * NB:(li + 1) * NB, c0:c0 + NB])
                     self._order(first_is_side=False)
@@ -906,7 +967,7 @@ class DistGP:
                         solve_block(k + 1, self.Xk[(k + 1) % 2])
                     lb = self._lstart(k + 1)                   # (b) my blocks beyond k+1
                     if self.nloc - lb > 0:
-                        with self._timed("update_v", None):
+                        with self._timed("update_v", None), self._ticket(True):      # the sweep has no whole-CU kernel
                             ops.gemm_nt(V[:, lb * NB:self.nloc * NB], Xk, A[lb * NB:self.nloc * NB, c0:c0 + NB])
                 self._order(first_is_side=True)
         self.dots.zero_()
@@ -988,8 +1049,8 @@ class DistGP:
         # ---- U^T sweep: column block k of U (rows < (k+1) NB are non-zero) <- block * L_kk^-T, then the later blocks
         for k in range(T):
             m = (k + 1) * NB
-            if self.rank == k % G:
-                li = k // G
+            if self.rank == self._own[k]:
+                li = self._li[k]
                 blk = U[:m, li * NB:(li + 1) * NB]
                 ops.trsm_block(A[li * NB:(li + 1) * NB, k * NB:(k + 1) * NB], blk)
                 if self.coll:
@@ -997,8 +1058,8 @@ class DistGP:
             if k == T - 1:
                 break
             if self.coll:
-                self.comm.broadcast(Xk[:m], k % G, tag=("ublock", k))
-            src = Xk[:m] if self.coll else U[:m, (k // G) * NB:(k // G + 1) * NB]
+                self.comm.broadcast(Xk[:m], self._own[k], tag=("ublock", k))
+            src = Xk[:m] if self.coll else U[:m, self._li[k] * NB:(self._li[k] + 1) * NB]
             ls = self._lstart(k)
             if self.nloc - ls > 0:
                 ops.gemm_nt(U[:m, ls * NB:self.nloc * NB], src, A[ls * NB:self.nloc * NB, k * NB:(k + 1) * NB])
@@ -1062,8 +1123,8 @@ class DistGP:
                     self.comm.all_gather(allp, part, tag=("alpha_part", k))
             else:
                 allp.copy_(part)
-            if self.rank == k % G:
-                li = k // G
+            if self.rank == self._own[k]:
+                li = self._li[k]
                 # rhs = m_k - (part_0 + part_1 + ... ): ONE launch of the library's own fixed-order sum (contributions added
                 # in rank order whatever the launch geometry: the same bits on every run and every rank)
                 with self._timed("alpha_solve", None):
@@ -1102,7 +1163,7 @@ class DistGP:
                 raise RuntimeError("DistGP.alpha: the one-launch backward solve gave up waiting for a block (non-finite factor?)")
         out = np.empty(self.Np)
         for b in range(T):
-            out[b * NB:(b + 1) * NB] = R[b % G, b // G]
+            out[b * NB:(b + 1) * NB] = R[self._own[b], self._li[b]]
         self.stage_ms["alpha"] = (time.perf_counter() - t_begin) * 1e3
         return out[:self.N].copy()
 

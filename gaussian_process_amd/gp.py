@@ -85,6 +85,14 @@ class GPContext:
         check(self._lib.gpmi_probe_panel(self._h, int(kind), int(m), int(reps), C.byref(us), st))
         return us.value, (np.array(st, dtype=np.uint64) if stamps else None)
 
+    def probe_trsv_giveup(self, n=1024, wait_ms=200.0):
+        """-> (err word, elapsed ms, x): the one-launch backward solve on an identity system whose bottom block is never
+        solved -- every wait must run into its bound, set the error word and leave the kernel"""
+        err, ms = C.c_int(-1), C.c_double()
+        x = np.empty(int(n))
+        check(self._lib.gpmi_probe_trsv_giveup(self._h, int(n), float(wait_ms), C.byref(err), C.byref(ms), ptr(x)))
+        return err.value, ms.value, x
+
     def probe_hbm_write(self, nbytes=1 << 30):
         v = C.c_double()
         check(self._lib.gpmi_probe_hbm_write(self._h, int(nbytes), C.byref(v)))

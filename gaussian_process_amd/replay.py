@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from .dist import DistGP, YB
+from .dist import DistGP, YB, block_layout
 
 
 class SoloComm:
@@ -72,19 +72,24 @@ class ReplaySource:
 
 
 class ReplayComm:
-    def __init__(self, rank, size, source: ReplaySource):
+    def __init__(self, rank, size, source: ReplaySource, layout="snake"):
         if not (0 <= rank < size):
             raise ValueError("rank must be in [0, size)")
         self.rank, self.size, self.src = int(rank), int(size), source
+        self.layout = layout
+        self._own, self._li, self._blocks = block_layout(source.T, self.size, layout)
+        dev = source.gp.dev
+        self._bidx = [torch.tensor(b, dtype=torch.int64, device=dev) for b in self._blocks]     # for gathers out of the source
         self._prep = None
         self.bytes = {"bcast": 0, "allgather": 0}      # what the absent ranks delivered, per kind
 
     # ---- the block ownership of dist.DistGP, for any rank q
     def _nblocks(self, q):
-        return len(range(q, self.src.T, self.size))
+        return len(self._blocks[q])
 
     def _lstart(self, k, q):
-        return 0 if k < q else (k - q) // self.size + 1
+        import bisect
+        return bisect.bisect_right(self._blocks[q], k)
 
     def _prepare(self):
         """messages that are sums over an absent rank's blocks: computed once, with the same primitives a rank uses"""
@@ -99,18 +104,19 @@ class ReplayComm:
         for q in range(G):
             nq = self._nblocks(q)
             if nq:
-                ops.sum_fixed(s.logdiag[q:], nq, 2 * G, 1, lml[q, 0:1])
-            if q == T % G:
+                mine = s.logdiag.index_select(0, self._bidx[q]).contiguous()      # rank q's blocks, in its local order
+                ops.sum_fixed(mine, nq, 2, 1, lml[q, 0:1])
+            if q == self._own[T]:
                 lml[q, 1:2].copy_(s.mtm[1:2])
         prep["lml"] = lml
         # backward solve (tag "alpha_part", k): for the blocks k this rank owns, the sum of the other ranks' contributions
         # sum_{j > k, j % G != r} L_jk^T alpha_j -- one gemv over the rows below with this rank's own alpha blocks zeroed
         am = s.alpha.clone()
-        for b in range(r, T, G):
+        for b in self._blocks[r]:
             am[b * NB:(b + 1) * NB].zero_()
         others = torch.zeros(max(self._nblocks(r), 1), NB, dtype=torch.float64, device=dev)
         scratch = torch.empty(max((T * NB + 63) // 64, 1) * NB, dtype=torch.float64, device=dev)
-        for li, k in enumerate(range(r, T, G)):
+        for li, k in enumerate(self._blocks[r]):
             r0 = (k + 1) * NB
             if r0 < T * NB:
                 ops.gemv_t(gp.A[r0:T * NB, k * NB:(k + 1) * NB], am[r0:T * NB], others[li], scratch)
@@ -125,9 +131,9 @@ class ReplayComm:
                 if q == r or nq == 0:
                     continue
                 Vq = torch.empty(n_p, nq * NB + 32, dtype=torch.float64, device=dev)
-                Vq[:, :nq * NB].view(n_p, nq, NB).copy_(V3[:, q::G])
+                Vq[:, :nq * NB].view(n_p, nq, NB).copy_(V3.index_select(1, self._bidx[q]))
                 mq = torch.empty(nq * NB, dtype=torch.float64, device=dev)
-                mq.view(nq, NB).copy_(gp.m[:T * NB].view(T, NB)[q::G])
+                mq.view(nq, NB).copy_(gp.m[:T * NB].view(T, NB).index_select(0, self._bidx[q]))
                 ops.row_dots(Vq, nq * NB, mq, dots[q, 0], dots[q, 1])
                 ops.sync()
                 del Vq, mq
@@ -175,8 +181,8 @@ class ReplayComm:
                 if q == r:
                     O[q, :cnt].copy_(inp.view(cmax, NB, NB)[:cnt])
                 else:
-                    b0 = q + self._lstart(k, q) * G
-                    O[q, :cnt].copy_(L3[b0::G][:cnt, :, k * NB:(k + 1) * NB])
+                    ls = self._lstart(k, q)
+                    torch.index_select(L3[:, :, k * NB:(k + 1) * NB], 0, self._bidx[q][ls:ls + cnt], out=O[q, :cnt])
                     self.bytes["allgather"] += cnt * NB * NB * 8
             return
         prep = self._prepare()
@@ -194,8 +200,8 @@ class ReplayComm:
             O = flat[:G * NB].view(G, NB)
             O.zero_()
             O[r].copy_(inp)
-            if k % G == r and G > 1:       # only the owner of block k reads the sum: the others' share goes into one slot
-                O[(r + 1) % G].copy_(prep["alpha_others"][k // G])
+            if self._own[k] == r and G > 1:       # only the owner of block k reads the sum: the others' share goes into one slot
+                O[(r + 1) % G].copy_(prep["alpha_others"][self._li[k]])
         elif kind == "alpha_full":
             cmax = n // NB
             O = flat[:G * cmax * NB].view(G, cmax, NB)
@@ -205,7 +211,7 @@ class ReplayComm:
                 if q == r:
                     O[q].copy_(inp.view(cmax, NB))
                 elif nq:
-                    O[q, :nq].copy_(A2[q::G])
+                    torch.index_select(A2, 0, self._bidx[q], out=O[q, :nq])
         else:
             raise NotImplementedError("ReplayComm.all_gather: no replay for %r" % (tag,))
 
@@ -220,9 +226,10 @@ class ReplayComm:
                            % (self.rank, self.size), "ranks": self.size, "env": {}}
 
 
-def replay_rank(device_index, source: ReplaySource, rank, size, X, y, Xs, lookahead=2, ops=None):
+def replay_rank(device_index, source: ReplaySource, rank, size, X, y, Xs, lookahead=2, ops=None, layout="snake"):
     """DistGP of rank `rank` in a world of `size`, its collectives served from `source`; train / test sets resident"""
-    gp = DistGP(device_index, nb=source.NB, comm=ReplayComm(rank, size, source), lookahead=lookahead, ops=ops)
+    gp = DistGP(device_index, nb=source.NB, comm=ReplayComm(rank, size, source, layout), lookahead=lookahead, ops=ops,
+                layout=layout)
     gp.set_train(X, y)
     if Xs is not None:
         gp.set_test(Xs)
@@ -236,7 +243,7 @@ def check_rank(gp, source: ReplaySource):
     NB, G, r = s.NB, gp.G, gp.rank
     out = {"L_rel": 0.0}
     scale = float(s.gp.A[:s.T * NB, :s.Np].abs().max().item())
-    for li, b in enumerate(range(r, s.T, G)):
+    for li, b in enumerate(gp.my_blocks):
         mine = torch.tril(gp.A[li * NB:(li + 1) * NB, :(b + 1) * NB], diagonal=b * NB)
         ref = torch.tril(s.gp.A[b * NB:(b + 1) * NB, :(b + 1) * NB], diagonal=b * NB)
         out["L_rel"] = max(out["L_rel"], float((mine - ref).abs().max().item()) / scale)

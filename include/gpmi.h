@@ -215,6 +215,11 @@ int gpmi_device_info(gpmi_ctx* ctx, double* out, int count);
  * m rows (trsm128); *out_us = microseconds per launch; stamps_out (64 entries or NULL) = in-kernel clock stamps
  * of one instrumented launch (layout: csrc/panel_mfma.hip) */
 int gpmi_probe_panel(gpmi_ctx* ctx, int kind, int64_t m, int reps, double* out_us, uint64_t* stamps_out);
+/* diagnostic: the give-up path of the one-launch backward solve.  An n x n identity system whose bottom block is
+ * deliberately never solved: every wait runs into its bound (wait_ms here, 10 s in the product), the kernel must set
+ * its error word (*err_out = 1), leave NaN in the entries it waited for (x_out, n doubles) and RETURN
+ * (*elapsed_ms: about wait_ms per dependent block in flight). */
+int gpmi_probe_trsv_giveup(gpmi_ctx* ctx, int64_t n, double wait_ms, int* err_out, double* elapsed_ms, double* x_out);
 
 /* ---------------------------------------------------------------------------
  * Device-pointer block primitives for the multi-GPU (row-block cyclic) driver
@@ -315,6 +320,10 @@ int gpmi_dev_trsv_lt_chain(void* stream, double* L_dev, int64_t ld, double* vsid
 /* on != 0: the block primitives called from this thread run beside a trailing update on another stream (lookahead)
  * and use their small-LDS forms, which fit on a CU next to an update workgroup; same results.  0 switches back. */
 int gpmi_dev_set_concurrent(int on);
+/* kernel-selection options (the gpmi_set_option names that choose between kernel forms: "gemm_ticket", "gemm_reserve",
+ * "gemm_persist", "panel_prio", ...) for the context-free block primitives called from THIS thread; same results
+ * whatever the choice.  The multi-rank driver switches its large update launches to the ticket form with it. */
+int gpmi_dev_set_option(const char* name, int64_t value);
 /* f2 on device pointers, one row chunk of the gradient trace (tune_hyperparms_regression.py:43-57):
  *   out2[0] += sum_ij W_ij dK_ij/dl,  out2[1] += sum_ij W_ij dK_ij/dsigma,
  *   W_ij = alpha_r[i] alpha_c[j] - kinv_sign * Kinv[(i - row0) * ld + j],  rows row0 .. row0 + nrows, all N columns.

@@ -524,21 +524,22 @@ def test_cfg5_64_triples_N32768(ctx, oracle):
         if s2 == 5e-4:
             assert T.compute_mar_likelihood(X, None, y, sf, l, ctx=ctx) == lml[t], (t, l, sf)
     # LML = -.5 m.m - sum log L_ii - N/2 log 2 pi is a sum of terms of 1e5 .. 5e6 that cancels to as little as 2e3 on this
-    # grid (triple 24: 2093.3), so "relative to |LML|" is the right scale only where nothing cancels: a triple passes at
-    # 1e-10 of |LML|, or else at 1e-10 of the magnitude of the terms it is the sum of (measured: 2.0e-11 of that at worst,
-    # triple (4, 2, 1e-4), cond ~ 1e9; two triples exceed 1e-10 of |LML|: 24 at 1.3e-9 and 28 at 2.1e-10)
+    # grid (triple 24: 2093.3), so "relative to |LML|" is the right scale only where nothing cancels.  Exactly TWO triples
+    # are known to cancel that far -- 24 = (2, 1.5, 1e-4) and 28 = (2, 2, 1e-4); measured 1.3e-9 and 2.1e-10 of |LML| -- and
+    # only those may be judged against the magnitude of the terms instead, which comes from the ORACLE, not from the path
+    # under test (tests/golden/oracle_cfg5_scales.npz, scripts/oracle_cfg5_scales.py: .5 m.m + |sum log L_ii| + N/2 log 2 pi
+    # = 2.85e5 and 2.70e5); every other triple must meet 1e-10 of |LML| itself.
+    sc = golden("oracle_cfg5_scales")
+    cancelling_known = {int(t): float(v) for t, v in zip(sc["triple_index"], sc["term_scale"])}
+    assert set(cancelling_known) == {24, 28} and int(sc["N"]) == N
     diff = np.abs(lml - g["lml"])
     rel = diff / np.abs(g["lml"])
-    cancelling = np.where(rel > LML_RTOL)[0]
-    print("cfg5 vs the oracle's 64 values: worst difference relative to |LML| %.2e (triple %d); %d triple(s) judged against "
-          "the magnitude of the LML's terms" % (rel.max(), int(rel.argmax()), len(cancelling)))
-    assert len(cancelling) <= 4
-    for t in cancelling:
-        l, sf, s2 = triples[t]
-        ctx.factorize(sf, l, s2)
-        m, dg = ctx.m(), ctx.diag()
-        scale = .5 * float(m @ m) + abs(float(np.log(dg).sum())) + N / 2.0 * np.log(2 * np.pi)
-        assert diff[t] <= LML_RTOL * scale, (int(t), float(diff[t]), scale)
+    print("cfg5 vs the oracle's 64 values: worst difference relative to |LML| %.2e (triple %d)" % (rel.max(), int(rel.argmax())))
+    for t in range(len(triples)):
+        if t in cancelling_known:
+            assert diff[t] <= LML_RTOL * cancelling_known[t], (t, float(diff[t]), cancelling_known[t])
+        else:
+            assert rel[t] <= LML_RTOL, (t, float(rel[t]))
 
 
 def test_d16_N8192_properties(ctx, oracle):
@@ -981,6 +982,46 @@ def test_backward_solve_one_launch_many_blocks_repeatable(ctx, oracle):
         ki = np.exp(-.125 * ((X - X[i]) ** 2).sum(1))
         ki[i] += 5e-4
         assert abs(ki @ a0 - y[i]) <= RESID_ATOL * max(1.0, np.abs(a0).max() * 1e-3)
+
+
+def test_backward_solve_one_launch_gives_up_cleanly(ctx):
+    """the give-up path of the one-launch backward solve: no finite or non-finite factor reaches it -- a NaN
+    block publishes NaN like any other value -- so a probe leaves the bottom block of an identity system unsolved
+    (gpmi_probe_trsv_giveup): every wave must run into its wall-clock bound, set the error word, leave NaN in what it
+    waited for and RETURN.  The product's bound is 10 s; the probe's is 150 ms."""
+    import time
+    t0 = time.perf_counter()
+    err, ms, x = ctx.probe_trsv_giveup(1024, 150.0)
+    assert err == 1
+    assert 140.0 <= ms <= 150.0 * 8 + 500.0, ms           # at most one bound per dependent block, never a hang
+    assert time.perf_counter() - t0 < 10.0
+    assert np.all(np.isnan(x[:1024 - 128]))                # every solved-block entry depended on the missing block
+    # and the context is alive afterwards: a real solve on it
+    X = np.random.default_rng(3).uniform(-1, 1, (700, 3))
+    y = np.sin(X.sum(1))
+    ctx.fit(X, y, 1.0, 1.0, 5e-4)
+    assert np.all(np.isfinite(ctx.alpha()))
+
+
+def test_dev_trsv_lt_chain_refuses_misaligned_views():
+    """gpmi_dev_trsv_lt_chain reads L and its side buffer with 16-byte loads: a view that starts on an odd column is
+    refused with an error, not read unaligned"""
+    import torch
+    from gaussian_process_amd.dist import HipBlockOps
+    ops = HipBlockOps(0)
+    n = 256
+    big = torch.zeros(n, n + 34, dtype=torch.float64, device="cuda")
+    big[:, 1:n + 1] = torch.eye(n, dtype=torch.float64, device="cuda")
+    b = torch.ones(n, dtype=torch.float64, device="cuda")
+    vs = torch.zeros(n * 128 + 2, dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.trsv_lt(big[:, 1:n + 1], b, inverted=False, vside=vs[:n * 128])        # L view at an odd column offset
+    ok = torch.eye(n, dtype=torch.float64, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.trsv_lt(ok, b, inverted=False, vside=vs[1:n * 128 + 1])                # side buffer off by one double
+    ops.trsv_lt(ok, b, inverted=False, vside=vs[:n * 128])                         # aligned: solves (identity: b unchanged)
+    torch.cuda.synchronize()
+    assert torch.equal(b, torch.ones(n, dtype=torch.float64, device="cuda"))
 
 
 @pytest.mark.parametrize("nrows,ncols,ld", [(5000, 512, 600), (128, 256, 256), (1300, 2048, 2112), (777, 130, 132), (64, 64, 67)])

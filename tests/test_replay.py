@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 
-def _replay_all_ranks(oracle, device, G, N, d, n, nb, la):
+def _replay_all_ranks(oracle, device, G, N, d, n, nb, la, layout="snake"):
+    from gaussian_process_amd.dist import block_layout
     from gaussian_process_amd.replay import ReplaySource, replay_rank, check_rank
     ops_of = None
     if device == "cpu":
@@ -22,7 +23,7 @@ def _replay_all_ranks(oracle, device, G, N, d, n, nb, la):
     assert np.max(np.abs(src.mu - ref["mu"])) <= 1e-9 and np.max(np.abs(src.var - ref["var"])) <= 1e-10
     amax = np.max(np.abs(ref["alpha"]))
     for r in range(G):
-        gp = replay_rank(0, src, r, G, X, y, Xs, lookahead=la, ops=ops_of() if ops_of else None)
+        gp = replay_rank(0, src, r, G, X, y, Xs, lookahead=la, ops=ops_of() if ops_of else None, layout=layout)
         for rep in range(2):                                  # a second step on resident data gives the same answers
             lml = gp.factorize(1.0, ell, 5e-4)
             alpha = gp.alpha()
@@ -39,14 +40,35 @@ def _replay_all_ranks(oracle, device, G, N, d, n, nb, la):
         # the absent ranks' messages had the sizes a real rank receives: per fit, the panel column below every block
         # column minus this rank's own share
         T = src.T
-        want = sum((len(range(q, T, G)) - (0 if k < q else (k - q) // G + 1)) for k in range(T - 1) for q in range(G) if q != r)
+        own = block_layout(T, G, layout)[0]
+        want = sum(1 for k in range(T - 1) for b in range(k + 1, T) if own[b] != r)
         assert gp.comm.bytes["allgather"] == 2 * want * nb * nb * 8, r
 
 
-@pytest.mark.parametrize("G,N,d,n,nb,la", [(2, 700, 3, 50, 128, 2), (3, 520, 2, 33, 128, 2), (8, 1100, 4, 20, 128, 2),
-                                           (8, 700, 3, 50, 128, 1), (4, 1100, 4, 20, 256, 0)])
-def test_replay_every_rank_cpu(oracle, G, N, d, n, nb, la):
-    _replay_all_ranks(oracle, "cpu", G, N, d, n, nb, la)
+@pytest.mark.parametrize("G,N,d,n,nb,la,layout", [(2, 700, 3, 50, 128, 2, "snake"), (3, 520, 2, 33, 128, 2, "snake"),
+                                                  (8, 1100, 4, 20, 128, 2, "snake"), (8, 700, 3, 50, 128, 1, "cyclic"),
+                                                  (4, 1100, 4, 20, 256, 0, "cyclic"), (4, 2300, 4, 20, 128, 2, "snake")])
+def test_replay_every_rank_cpu(oracle, G, N, d, n, nb, la, layout):
+    _replay_all_ranks(oracle, "cpu", G, N, d, n, nb, la, layout)
+
+
+def test_snake_layout_balances_the_update():
+    """block_layout: every block owned once, local indices consistent, and the snake's worst rank within 3 % of the mean
+    share of the update at north_star's shape (64 blocks, 8 ranks) where cyclic dealing is 17 % over"""
+    from gaussian_process_amd.dist import block_layout
+    for T, G in ((64, 8), (32, 4), (6, 8), (9, 8), (5, 3), (1, 2), (128, 8)):
+        for layout in ("cyclic", "snake"):
+            own, li, blocks = block_layout(T, G, layout)
+            assert sorted(b for bl in blocks for b in bl) == list(range(T)) and len(own) == T + 1
+            for r in range(G):
+                assert blocks[r] == sorted(blocks[r]) and all(own[b] == r and li[b] == j for j, b in enumerate(blocks[r]))
+                assert abs(len(blocks[r]) - T / G) < 1
+            assert li[T] == len(blocks[own[T]])
+    share = lambda bl: sum(b * (b + 1) // 2 for b in bl)
+    for layout, worst in (("cyclic", 1.169), ("snake", 1.026)):
+        _, _, blocks = block_layout(64, 8, layout)
+        w = [share(bl) for bl in blocks]
+        assert abs(max(w) / (sum(w) / 8) - worst) < 2e-3, (layout, max(w) / (sum(w) / 8))
 
 
 @pytest.mark.gpu
