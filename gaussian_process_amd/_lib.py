@@ -64,6 +64,7 @@ SIGNATURES = {
     "gpmi_probe_hbm_ex": [_vp, _i64, C.c_int, C.c_int, _dp],
     "gpmi_device_info": [_vp, _dp, C.c_int],
     "gpmi_probe_panel": [_vp, C.c_int, _i64, C.c_int, _dp, C.POINTER(C.c_uint64)],
+    "gpmi_probe_launch_storm": [_vp, C.c_int, C.c_int, C.c_double, C.c_int],
     "gpmi_probe_trsv_giveup": [_vp, _i64, C.c_double, C.POINTER(C.c_int), _dp, _dp],
     "gpmi_dev_rbf_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, C.c_double, _vp, _i64],
     "gpmi_dev_rbf_cross": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _vp, _i64],
@@ -85,6 +86,14 @@ SIGNATURES = {
     "gpmi_dev_set_option": [C.c_char_p, _i64],
     "gpmi_dev_grad_trace": [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, C.c_double, C.c_double, C.c_double, _vp, _vp],
     "gpmi_dev_row_dots": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "gpmi_comm_load": [C.c_char_p],
+    "gpmi_comm_library": [C.c_char_p, _i64, C.POINTER(C.c_int)],
+    "gpmi_comm_unique_id": [C.c_char_p],
+    "gpmi_comm_create": [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)],
+    "gpmi_comm_destroy": [_vp],
+    "gpmi_comm_broadcast": [_vp, _vp, _vp, _i64, C.c_int],
+    "gpmi_comm_all_gather": [_vp, _vp, _vp, _vp, _i64],
+    "gpmi_comm_all_reduce": [_vp, _vp, _vp, _i64, C.c_int, C.c_int],
     "gpmi_dev_sum_fixed": [_vp, _vp, _i64, _i64, _i64, _vp, C.c_double, _vp],
     "gpmi_dev_axpy2d": [_vp, _vp, _i64, _vp, _i64, _i64, _i64, C.c_double],
 }

@@ -62,7 +62,6 @@ struct GemmDmaDev {
     // persistent form: work counters of this launch (one per XCD) and the number of virtual blocks
     struct PersistSlot* slot;
     int nblocks;
-    int stagger;                  // per-tile form, experiment (option gemm_stagger): phases the first round's workgroups are spread over
 };
 
 // Work counters of one persistent launch: workgroups on XCD x draw block numbers 8 w + x from ctr[x]; the last
@@ -148,14 +147,6 @@ __device__ __forceinline__ void gemm_nt_dma_body(const GemmDmaDev& p) {
     } else {
         live = dma_map_tile(p, ti, tj) && dma_tile_live(p, ti, tj);
         if (!live) return;
-        // experiment: the tiles of a launch start and end in step, so a kernel of the other stream that needs a whole CU
-        // waits for the next ROUND boundary (half a tile time on average).  Holding part of the first round back by a
-        // fraction of a tile time spreads the boundaries: stagger phases, (tile time) / stagger apart.
-        if (p.stagger > 1 && blockIdx.x < 320) {
-            const int ph = (int)((blockIdx.x >> 3) % (unsigned)p.stagger);
-            const int naps = ph * p.nchunks / (2 * p.stagger);        // ~8k cycles each; a K step of 16 takes ~4.2k
-            for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
-        }
     }
    if (live) {
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
@@ -742,7 +733,6 @@ struct GemmSmallDev {
     int Tm, Tn, nchunks;
     int lower;
     int64_t diag_off;
-    int prio;
 };
 
 template <int SM_STAGES>
@@ -753,7 +743,6 @@ __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmSmallDev p
         const int64_t min_col = (int64_t)tj * SM_T, max_row = (int64_t)ti * SM_T + SM_T - 1;
         if (min_col > max_row + p.diag_off) return;
     }
-    if (p.prio) __builtin_amdgcn_s_setprio(3);     // option panel_prio (beside a trailing update only)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -851,7 +840,6 @@ hipError_t launch_gemm_nt_small(hipStream_t s, const GemmArgs& a) {
     p.C = a.C; p.A = a.A; p.B = a.B; p.ldc = a.ldc; p.lda = a.lda; p.ldb = a.ldb;
     p.Tm = (int)(a.M / SM_T); p.Tn = (int)(a.N / SM_T); p.nchunks = (int)(a.K / 16);
     p.lower = a.lower; p.diag_off = a.diag_off;
-    p.prio = (t_small_shallow && tuning().panel_prio) ? 1 : 0;
     constexpr size_t lds8 = (size_t)8 * SM_STAGE_SLOTS * 16, lds3 = (size_t)3 * SM_STAGE_SLOTS * 16;
     static PerDeviceOnce once;
     const hipError_t ea = once.run([&]() -> hipError_t {
@@ -940,7 +928,6 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     p.stamps = tn.gemm_stamps;
     p.slot = nullptr;
     p.nblocks = nblocks;
-    p.stagger = (tn.gemm_stagger > 1 && a.role == 1 && gemm_two_streams_active() && nblocks >= 512) ? tn.gemm_stagger : 0;
     // persistent form: launches with at least two rounds of tiles and a K loop long enough to draw the successor in --
     // and the chip to themselves: resident workgroups (216 registers per lane, two waves per SIMD) leave no room on a
     // CU for the panel kernels of the other stream, which would then wait for the whole launch instead of a tile

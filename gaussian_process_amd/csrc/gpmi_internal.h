@@ -20,8 +20,6 @@ struct Tuning {
     int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
     int gemm_persist = 1;       // resident workgroups that chain the K loops of consecutive tiles (launches with >= 2 rounds of tiles)
     int gemm_ticket = 0;        // ticket form of the per-tile kernel (resident workgroups, tiles drawn from counters, no state across tiles): 1 Cholesky trailing updates under lookahead, 2 every launch of at least one round
-    int panel_prio = 0;         // 1: trsm128 and the small GEMM raise their waves' issue priority (s_setprio 3) -- for the forms that share CUs with a trailing update
-    int gemm_stagger = 0;       // experiment: spread the first round of a trailing update under lookahead over this many phases (0 / 1: off)
     int gemm_reserve = 0;       // ticket form: CUs per XCD the launch leaves untouched (for the panel kernels of the other stream)
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always

@@ -439,9 +439,8 @@ __device__ __forceinline__ void stage_l_tiles(const double* L, int64_t ldl, d2* 
 
 template <int PHASE>
 __global__ __launch_bounds__(256, 2) void trsm128_kernel(const double* L, int64_t ldl, double* X, int64_t ldx,
-                                                          int64_t nslabs, unsigned long long* stamps, int prio) {
+                                                          int64_t nslabs, unsigned long long* stamps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (prio) __builtin_amdgcn_s_setprio(3);       // option panel_prio: issue priority over the update's waves on a shared SIMD
     d2* tiles = reinterpret_cast<d2*>(smem);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -587,13 +586,13 @@ hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X
     const unsigned grid = (unsigned)std::min<int64_t>(nslabs, 512);     // two workgroups per CU (72 KiB of LDS each)
     if (gemm_shallow_active()) {            // beside a trailing update: two launches that fit next to its workgroups
         hipLaunchKernelGGL(trsm128_kernel<0>, dim3(grid), dim3(256), trsm_tiles<0>() * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
-                           tuning().panel_stamps, tuning().panel_prio);
+                           tuning().panel_stamps);
         hipLaunchKernelGGL(trsm128_kernel<1>, dim3(grid), dim3(256), trsm_tiles<1>() * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
-                           tuning().panel_stamps, tuning().panel_prio);
+                           tuning().panel_stamps);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(trsm128_kernel<-1>, dim3(grid), dim3(256), NTILES * TILE_BYTES, s, L, ldl, X, ldx, nslabs,
-                       tuning().panel_stamps, tuning().panel_prio);
+                       tuning().panel_stamps);
     return hipGetLastError();
 }
 

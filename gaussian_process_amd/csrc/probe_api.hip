@@ -325,6 +325,41 @@ int gpmi_probe_resident(gpmi_ctx* c, int high_priority, int lds_bytes, int threa
     return GPMI_OK;
 }
 
+// A storm of tiny kernels on a stream of its own: `count` launches of a one-wave kernel, `sleep_us` microseconds long
+// each (kind 0: it only sleeps; 1: an agent-scope release + acquire fence pair as well; 2: an agent-scope atomic store
+// as well).  Returns at once; time something else (gpmi_probe_gemm) meanwhile to see what the KERNEL BOUNDARIES of a
+// busy second stream -- the runtime brackets every kernel with cache maintenance -- cost a long-running update GEMM
+// (the resident panel chain of round 3 doubled the launches on the panel stream).
+__global__ void probe_tiny_kernel(unsigned long long ticks, int kind, unsigned long long* flag) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (kind == 1 && threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (kind == 2 && threadIdx.x == 0) __hip_atomic_store(flag, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+int gpmi_probe_launch_storm(gpmi_ctx* c, int high_priority, int count, double sleep_us, int kind) {
+    if (!c || count < 1 || count > 200000 || sleep_us < 0.0 || sleep_us > 1000.0 || kind < 0 || kind > 2)
+        return fail_arg("gpmi_probe_launch_storm: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(c->red.ensure(16 * 8));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high_priority ? hi : lo));
+    hipError_t e = hipSuccess;
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->red.as<double>() + 12);
+    for (int i = 0; i < count && e == hipSuccess; ++i) {
+        hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)(sleep_us * 100.0), kind, flag);
+        e = hipGetLastError();
+    }
+    (void)hipStreamDestroy(st);          // released when the kernels have finished
+    if (e != hipSuccess) return fail_runtime(e, "probe_tiny launch");
+    return GPMI_OK;
+}
+
 int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {
     return gpmi_probe_hbm_ex(c, bytes, 0, 2048, gbps);
 }

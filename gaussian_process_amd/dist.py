@@ -114,6 +114,93 @@ class TorchComm:
         return {"backend": dist.get_backend(self.group), "ranks": self.size, "env": knobs}
 
 
+class RcclComm:
+    """The same five members straight on RCCL through the C-ABI (gpmi_comm_*: libgpmi355x.so opens librccl itself and
+    issues every collective on the CALLER'S stream -- no process-group layer, no internal communication stream).
+    north_star: "a thin C-ABI ... RCCL broadcast/all-gather of panel columns over xGMI".
+
+    A communicator must not run two collectives at once, and the schedule issues collectives from three streams (main,
+    side, crit) so that a broadcast of the next diagonal block does not queue behind the all-gather of the current panel:
+    there is one communicator per stream, handed out in the order the streams first call in -- the same order on every
+    rank, since every rank runs the same program.  torch.distributed (any backend; gloo will do) is only the side
+    channel that carries rank 0's 128-byte ncclUniqueIds to the others; a world of one rank needs none."""
+
+    NCOMM = 3
+
+    def __init__(self, device_index, rank=None, size=None, group=None):
+        self.lib = _lib.load()
+        if rank is None:
+            if dist.is_initialized():
+                rank, size = dist.get_rank(group), dist.get_world_size(group)
+            else:
+                rank, size = 0, 1
+        self.rank, self.size, self.group = int(rank), int(size), group
+        self.device_index = int(device_index)
+        if self.size > 1 and not dist.is_initialized():
+            raise RuntimeError("RcclComm over more than one rank needs torch.distributed (any backend) for the id exchange")
+        self._comms = []
+        for i in range(self.NCOMM):
+            idb = C.create_string_buffer(128)
+            if self.rank == 0:
+                check(self.lib.gpmi_comm_unique_id(idb))
+            if self.size > 1:
+                box = [idb.raw]
+                dist.broadcast_object_list(box, src=self._src(0), group=group)
+                idb = C.create_string_buffer(box[0], 128)
+            h = C.c_void_p()
+            check(self.lib.gpmi_comm_create(idb, self.rank, self.size, self.device_index, C.byref(h)))
+            self._comms.append(h)
+        self._by_stream = {}
+
+    def _src(self, r):
+        return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+    def close(self):
+        for h in self._comms:
+            self.lib.gpmi_comm_destroy(h)
+        self._comms = []
+
+    def _where(self):
+        """(communicator of the current stream, the stream)"""
+        st = torch.cuda.current_stream().cuda_stream
+        idx = self._by_stream.setdefault(st, min(len(self._by_stream), self.NCOMM - 1))
+        return self._comms[idx], C.c_void_p(st)
+
+    @staticmethod
+    def _flat(t):
+        if not t.is_contiguous():
+            raise ValueError("RcclComm: collectives take contiguous tensors")
+        return C.c_void_p(t.data_ptr()), t.numel() * t.element_size()
+
+    def broadcast(self, t, src, tag=None):
+        comm, st = self._where()
+        p, nbytes = self._flat(t)
+        check(self.lib.gpmi_comm_broadcast(comm, st, p, nbytes, int(src)))
+
+    def all_gather(self, out, inp, tag=None):
+        comm, st = self._where()
+        pi, nb_in = self._flat(inp)
+        po, nb_out = self._flat(out)
+        if nb_out < nb_in * self.size:
+            raise ValueError("RcclComm.all_gather: the receive buffer is too small")
+        check(self.lib.gpmi_comm_all_gather(comm, st, pi, po, nb_in))
+
+    def all_reduce(self, t, op="sum", tag=None):
+        comm, st = self._where()
+        p, _ = self._flat(t)
+        dt = {torch.float64: 0, torch.int64: 1}[t.dtype]
+        check(self.lib.gpmi_comm_all_reduce(comm, st, p, t.numel(), dt, {"sum": 0, "min": 1, "max": 2}[op]))
+
+    def describe(self):
+        import os
+        buf, ver = C.create_string_buffer(512), C.c_int()
+        self.lib.gpmi_comm_library(buf, 512, C.byref(ver))
+        knobs = {k: v for k, v in os.environ.items()
+                 if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC", "HSA_FORCE_FINE_GRAIN"))}
+        return {"backend": "rccl through the C-ABI (gpmi_comm_*), one communicator per stream", "ranks": self.size,
+                "library": buf.value.decode("utf-8", "replace"), "nccl_version": ver.value, "env": knobs}
+
+
 class HipBlockOps:
     """Block primitives on torch CUDA tensors through libgpmi355x.so (gpmi_dev_*).
     Views must be float64 with unit column stride; ld = view.stride(0)."""
@@ -291,7 +378,11 @@ class DistGP:
         self.layout = layout if layout is not None else os.environ.get("GPMI_DIST_LAYOUT", "snake")
         if self.layout not in ("cyclic", "snake"):
             raise ValueError("layout must be 'cyclic' or 'snake'")
-        self.comm = comm if comm is not None else TorchComm(group)
+        # collectives: an object with TorchComm's five members; default by $GPMI_DIST_COMM: "torch" (RCCL through
+        # torch.distributed's process group) or "rccl" (RCCL through this library's own C-ABI, RcclComm)
+        if comm is None:
+            comm = RcclComm(device_index, group=group) if os.environ.get("GPMI_DIST_COMM", "torch") == "rccl" else TorchComm(group)
+        self.comm = comm
         self.group = group
         self.rank = self.comm.rank
         self.G = self.comm.size
@@ -311,7 +402,9 @@ class DistGP:
         # large update launches in the ticket form of the GEMM (resident workgroups that draw tiles from per-XCD counters and
         # take over the other XCDs' tails -- a rank's staircase of row blocks is dealt unevenly to the XCDs): on wherever no
         # kernel of another stream needs a whole CU meanwhile, i.e. not while this rank factors a diagonal block
-        self.ticket = int(os.environ.get("GPMI_DIST_TICKET", "1"))
+        # -- measured on the 8-rank replay: the update itself runs 5-10 % faster, the panel solves that share the CUs with
+        # the resident workgroups 2-3x slower, the step not faster (profiles/r04_replay_ticket_ab.txt): off by default
+        self.ticket = int(os.environ.get("GPMI_DIST_TICKET", "0"))
         self.have_factor = False
         self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
         self._vside = {}             # local diagonal block -> its inverses' side buffer (one-launch backward solve)

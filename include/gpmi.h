@@ -215,6 +215,11 @@ int gpmi_device_info(gpmi_ctx* ctx, double* out, int count);
  * m rows (trsm128); *out_us = microseconds per launch; stamps_out (64 entries or NULL) = in-kernel clock stamps
  * of one instrumented launch (layout: csrc/panel_mfma.hip) */
 int gpmi_probe_panel(gpmi_ctx* ctx, int kind, int64_t m, int reps, double* out_us, uint64_t* stamps_out);
+/* diagnostic: `count` one-wave kernels of sleep_us microseconds each on a stream of their own (high_priority != 0: the
+ * device's highest priority), back to back; kind 0 sleep only, 1 + an agent-scope release / acquire fence pair, 2 + an
+ * agent-scope atomic store.  Returns at once: time gpmi_probe_gemm meanwhile to see what a second stream's kernel
+ * boundaries cost a long-running GEMM. */
+int gpmi_probe_launch_storm(gpmi_ctx* ctx, int high_priority, int count, double sleep_us, int kind);
 /* diagnostic: the give-up path of the one-launch backward solve.  An n x n identity system whose bottom block is
  * deliberately never solved: every wait runs into its bound (wait_ms here, 10 s in the product), the kernel must set
  * its error word (*err_out = 1), leave NaN in the entries it waited for (x_out, n doubles) and RETURN
@@ -349,6 +354,32 @@ int gpmi_dev_sum_fixed(void* stream, const double* in_dev, int64_t count, int64_
  * (GP_regression.py:154), the all-reduced -v^T v added onto the covariance rows */
 int gpmi_dev_axpy2d(void* stream, double* Y_dev, int64_t ldy, const double* X_dev, int64_t ldx, int64_t rows,
                     int64_t cols, double a);
+
+/* ---------------------------------------------------------------------------
+ * RCCL behind the C-ABI: the collectives of the row-block partitioned path (broadcast of a
+ * factored diagonal block, all-gather of a panel column over xGMI, the small all-reduces) issued on the CALLER'S stream,
+ * straight into librccl -- opened at run time (dlopen), never linked, so the library loads on hosts without it and binds
+ * the copy of RCCL a process already carries (PyTorch ships one next to its HIP runtime).  One communicator must not be
+ * used from two streams at once; the multi-rank driver keeps one per stream (gaussian_process_amd/dist.py: RcclComm).
+ * All sizes in bytes except gpmi_comm_all_reduce.
+ * ------------------------------------------------------------------------- */
+typedef struct gpmi_comm gpmi_comm;
+/* optional: the librccl to bind (absolute path); without it the first call looks for a copy already in the process,
+ * then for librccl.so.1 on the loader's path ($GPMI_RCCL_LIB overrides) */
+int gpmi_comm_load(const char* librccl_path);
+/* which library was bound (out: cap bytes) and its ncclGetVersion (may be NULL) */
+int gpmi_comm_library(char* out, int64_t cap, int* version);
+/* rank 0: a fresh ncclUniqueId (128 bytes) to hand to every rank by any side channel */
+int gpmi_comm_unique_id(char* id128);
+/* collective over the `size` ranks that hold the same id: ncclCommInitRank on `device` */
+int gpmi_comm_create(const char* id128, int rank, int size, int device, gpmi_comm** out);
+int gpmi_comm_destroy(gpmi_comm* comm);
+/* every rank's buf_dev (nbytes) <- root's */
+int gpmi_comm_broadcast(gpmi_comm* comm, void* stream, void* buf_dev, int64_t nbytes, int root);
+/* recv_dev (size * nbytes_per_rank) <- every rank's send_dev (nbytes_per_rank), in rank order */
+int gpmi_comm_all_gather(gpmi_comm* comm, void* stream, const void* send_dev, void* recv_dev, int64_t nbytes_per_rank);
+/* in place over `count` elements; dtype 0 float64, 1 int64; op 0 sum, 1 min, 2 max */
+int gpmi_comm_all_reduce(gpmi_comm* comm, void* stream, void* buf_dev, int64_t count, int dtype, int op);
 
 #ifdef __cplusplus
 }

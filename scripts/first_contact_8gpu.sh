@@ -10,8 +10,8 @@ mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0 GPMI_BENCH_DEADLINE_S=${GPMI_BENCH_DEADLINE_S:-300} GPMI_BENCH_STALL_S=${GPMI_BENCH_STALL_S:-90}
 say() { echo "[first contact] $*" | tee -a $OUT/log.txt; }
 
-say "1/4 two ranks, one GPU each, RCCL: tests/test_dist.py::test_two_ranks_rccl_one_gpu_each"
-timeout -k 10 600 python3 -m pytest tests/test_dist.py -x -q -m gpu -k two_ranks_rccl_one_gpu_each > $OUT/1_pytest.txt 2>&1 \
+say "1/4 two ranks, one GPU each, RCCL: tests/test_dist.py::test_two_ranks_rccl_one_gpu_each (+ the C-ABI binding)"
+timeout -k 10 600 python3 -m pytest tests/test_dist.py -x -q -m gpu -k "two_ranks_rccl" > $OUT/1_pytest.txt 2>&1 \
     || { say "FAILED at stage 1 (see $OUT/1_pytest.txt)"; tail -30 $OUT/1_pytest.txt; exit 1; }
 tail -3 $OUT/1_pytest.txt
 
@@ -25,8 +25,14 @@ timeout -k 10 400 python3 bench.py --gpus $NG --size 16384 --ntest 1024 --steps 
     || { say "FAILED at stage 3 (see $OUT/3_bench_gN_small.err)"; tail -40 $OUT/3_bench_gN_small.err; exit 3; }
 cut -c1-300 $OUT/3_bench_gN_small.json
 
+say "3b/4 the same through this library's own RCCL binding (GPMI_DIST_COMM=rccl; not fatal: the line above is the default path)"
+GPMI_DIST_COMM=rccl timeout -k 10 400 python3 bench.py --gpus $NG --size 16384 --ntest 1024 --steps 1 --warmup 0 > $OUT/3b_bench_gN_small_cabi.json 2> $OUT/3b_bench_gN_small_cabi.err \
+    && cut -c1-300 $OUT/3b_bench_gN_small_cabi.json || { say "stage 3b failed (see $OUT/3b_bench_gN_small_cabi.err); continuing with the default backend"; tail -20 $OUT/3b_bench_gN_small_cabi.err; }
+
 say "4/4 the real line: bench.py --gpus $NG (N=65536)"
 timeout -k 10 560 python3 bench.py --gpus $NG --steps 3 --warmup 1 > $OUT/4_bench_gN.json 2> $OUT/4_bench_gN.err \
     || { say "FAILED at stage 4 (see $OUT/4_bench_gN.err)"; tail -40 $OUT/4_bench_gN.err; exit 4; }
 cut -c1-400 $OUT/4_bench_gN.json
+GPMI_DIST_COMM=rccl timeout -k 10 560 python3 bench.py --gpus $NG --steps 3 --warmup 1 > $OUT/4b_bench_gN_cabi.json 2> $OUT/4b_bench_gN_cabi.err \
+    && cut -c1-400 $OUT/4b_bench_gN_cabi.json || say "the C-ABI backend at full size failed (see $OUT/4b_bench_gN_cabi.err)"
 say "all four stages passed"

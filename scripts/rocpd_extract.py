@@ -49,6 +49,16 @@ def traffic(fdb, wdb, out, kernel="chol_trailing_update_dma_kernel"):
            "total_fetch_bytes": 2.0 * 1024.0 * sum(v for v, _ in f),
            "total_write_bytes": 1024.0 * sum(v for v, _ in w),
            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 1 --warmup 0"}
+    # the source the counters describe: bench.py marks roofline.traffic "stale" when this file has changed since
+    import hashlib, os
+    src = os.path.join("gaussian_process_amd", "csrc", "gemm_dma.hip")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        res["kernel_source_sha256"] = hashlib.sha256(open(os.path.join(root, src), "rb").read()).hexdigest()
+        res["kernel_source"] = src
+    except OSError:
+        pass
+    res["git"] = os.environ.get("GPMI_GIT_REV")
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

@@ -71,3 +71,24 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "gp_oracle" not in text and "rbf_oracle" not in text, f
+
+
+def test_rccl_binding_resolves_without_linking():
+    """gpmi_comm_*: libgpmi355x.so does not link librccl (it must load on hosts without it); the first call opens it at
+    run time -- the copy already in the process when PyTorch brought one -- and reports which; creating a communicator
+    without a GPU fails with a status, never a crash"""
+    import subprocess
+    from gaussian_process_amd import _lib
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" not in needed and "libtorch" not in needed
+    lib = _lib.load()
+    buf, ver = C.create_string_buffer(512), C.c_int()
+    assert lib.gpmi_comm_library(buf, 512, C.byref(ver)) == _lib.GPMI_OK, _lib.last_error()
+    assert b"rccl" in buf.value and ver.value > 20000
+    n = C.c_int(-1)
+    if lib.gpmi_device_count(C.byref(n)) == _lib.GPMI_OK and n.value > 0:
+        pytest.skip("a GPU is present")
+    h = C.c_void_p()
+    idb = C.create_string_buffer(128)
+    assert lib.gpmi_comm_create(idb, 0, 1, 0, C.byref(h)) == _lib.GPMI_ERR_RUNTIME
+    assert lib.gpmi_comm_create(idb, 3, 2, 0, C.byref(h)) == _lib.GPMI_ERR_BAD_ARG

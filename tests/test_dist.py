@@ -295,6 +295,31 @@ def test_two_ranks_rccl_one_gpu_each(oracle, tmp_path, la):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs on one node (RCCL between ranks)")
+def test_two_ranks_rccl_through_the_c_abi(oracle, tmp_path):
+    """the same with the collectives issued through this library's own RCCL binding (gpmi_comm_*, dist.RcclComm: one
+    communicator per stream, no process-group layer); gloo only carries the ncclUniqueIds"""
+    os.environ["GPMI_DIST_COMM"] = "rccl"
+    try:
+        res = _run(2, "gloo", "cuda_per_rank", tmp_path, 6144, 8, 128, 512, lookahead=2)
+    finally:
+        os.environ.pop("GPMI_DIST_COMM", None)
+    _check(res, oracle, 6144, 8, 128)
+
+
+@pytest.mark.gpu
+def test_rccl_through_the_c_abi_on_a_world_of_one():
+    """gpmi_comm_* (librccl opened at run time by libgpmi355x.so, collectives on the caller's streams, one communicator
+    per stream): every collective of the multi-rank schedule on communicators of size 1 on the one GPU of the test box;
+    results equal the run without collectives bit for bit, for every lookahead level"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "nccl_world1.py"), "3072", "rccl"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "RCCL world-1 path: OK" in p.stdout and "rccl through the C-ABI" in p.stdout
+
+
+@pytest.mark.gpu
 def test_rccl_collectives_on_a_world_of_one():
     """The RCCL call path itself (backend "nccl": broadcast, all_gather_into_tensor, int64 MIN all_reduce,
     asynchronous stream semantics over the three streams of the schedule) on the one GPU of the test box:

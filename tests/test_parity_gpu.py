@@ -1071,3 +1071,30 @@ def test_persistent_update_gemm_gives_the_same_bits(ctx, oracle, N, n):
     ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 1.6, 5e-4)
     assert abs(out[1][0] - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
     assert np.max(np.abs(out[1][1] - ref["mu"])) <= MU_ATOL
+
+
+@pytest.mark.parametrize("N,n,opts", [(9000, 300, {"gemm_ticket": 2}), (9000, 300, {"gemm_ticket": 2, "gemm_reserve": 3}),
+                                      (16384, 256, {"gemm_ticket": 1}), (16384, 256, {"gemm_ticket": 1, "gemm_reserve": 2})])
+def test_ticket_update_gemm_gives_the_same_bits(ctx, oracle, N, n, opts):
+    """the ticket form of the update GEMM (round 4: resident workgroups that draw tiles from per-XCD counters and take over
+    the other XCDs' tails, optionally leaving gemm_reserve CUs per XCD untouched) runs the per-tile kernel's code tile for
+    tile: LML, mean, variance and alpha bit for bit, with one stream (gemm_ticket 2, N below the lookahead threshold) and
+    for the Cholesky's trailing updates under lookahead (gemm_ticket 1)"""
+    X, y, Xs = oracle.synthetic_problem(N, 8, n, seed=N + n)
+    out = []
+    for on in (False, True):
+        if on:
+            for k, v in opts.items():
+                ctx.set_option(k, v)
+        else:
+            ctx.set_option("gemm_persist", 0)
+        try:
+            lml = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+            mu, var = ctx.predict(Xs, want_sd=False)
+            out.append((lml, mu.copy(), var.copy(), ctx.alpha()))
+        finally:
+            ctx.set_option("gemm_persist", 1)
+            for k in opts:
+                ctx.set_option(k, 0)
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
