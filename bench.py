@@ -35,6 +35,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the pool's host driver only supports dmabuf IPC (RCCL / cross-process device memory)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# hardware queues per stream-priority level (gaussian_process_amd/_lib.py says why); before anything initialises HIP
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 # BASELINE.json's metric, verbatim (it names two quantities: `value` carries the TFLOP/s, `seconds` the time)
 BASELINE_METRIC = "GP-fit+predict sec and achieved fp64 TFLOP/s, N=65536 d=8, 1/2/4/8 MI355X"

@@ -11,6 +11,12 @@ import os
 
 import numpy as np
 
+# The HIP runtime maps streams onto a pool of hardware queues per priority level, 4 by default: the fifth stream of a level
+# that gets used shares a queue with an earlier one and their kernels run one after the other (profiles/r04_stream_overlap.txt;
+# it cost a second DistGP instance 20 % before its streams were shared).  Eight per level leaves room for three batch lanes,
+# a context and the partitioned driver in one process.  Read by the runtime when it initialises: set before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpmi355x.so")
 
@@ -64,6 +70,7 @@ SIGNATURES = {
     "gpmi_probe_hbm_ex": [_vp, _i64, C.c_int, C.c_int, _dp],
     "gpmi_device_info": [_vp, _dp, C.c_int],
     "gpmi_probe_panel": [_vp, C.c_int, _i64, C.c_int, _dp, C.POINTER(C.c_uint64)],
+    "gpmi_probe_stream_overlap": [_vp, C.c_int, C.c_int, C.c_double, _dp],
     "gpmi_probe_launch_storm": [_vp, C.c_int, C.c_int, C.c_double, C.c_int],
     "gpmi_probe_trsv_giveup": [_vp, _i64, C.c_double, C.POINTER(C.c_int), _dp, _dp],
     "gpmi_dev_rbf_rows": [_vp, _vp, _i64, _i64, _i64, _i64, _i64, C.c_double, C.c_double, C.c_double, _vp, _i64],

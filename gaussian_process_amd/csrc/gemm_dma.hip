@@ -902,13 +902,26 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
     p.b_block_off = a.b_block_off;
     p.b_block_tiles = a.b_block_off ? (int)(a.b_block_rows / 128) : 1;
     if (a.b_block_off && (a.b_block_rows <= 0 || a.b_block_rows % 128)) return hipErrorInvalidValue;
+    const Tuning& tn = tuning();
     TilePlan plan;
+    // the launch geometry: first as a resident form wants it (widest supertiles), which also decides whether one is used
     if (!plan_tiles(plan, p.Tm, p.Tn, a.lower, a.diag_off, a.row_ncols != nullptr, a.row_ncols_host, a.row_bands,
-                    p.row_block_tiles))
+                    p.row_block_tiles, 0, false))
+        return hipErrorInvalidValue;
+    if (plan.nsuper == 0) return hipSuccess;
+    const bool eight = tn.gemm_dma_waves == 8 && !(tn.gemm_dbg & 0xff);
+    const bool want_ticket = eight && (tn.gemm_ticket >= 2 || (tn.gemm_ticket == 1 && a.role == 1 && gemm_two_streams_active()));
+    const bool want_persist = eight && tn.gemm_persist && a.K >= 256 && !gemm_two_streams_active();
+    PersistPool* pool = (want_ticket || want_persist) ? persist_pool() : nullptr;
+    const bool ticket = want_ticket && pool && plan.nblocks >= pool->groups;
+    const bool persist = !ticket && want_persist && pool && plan.nblocks >= 2 * pool->groups;
+    // one workgroup per tile: the supertile edge is chosen with the static deal of blocks to the XCDs in mind
+    if (!ticket && !persist &&
+        !plan_tiles(plan, p.Tm, p.Tn, a.lower, a.diag_off, a.row_ncols != nullptr, a.row_ncols_host, a.row_bands,
+                    p.row_block_tiles, 0, tn.gemm_balance != 0))
         return hipErrorInvalidValue;
     p.S = plan.S; p.logS = plan.logS; p.SM = plan.SM; p.SN = plan.SN; p.tri = plan.tri; p.nsuper = plan.nsuper;
     if (plan.tri == 2) std::copy(plan.sprefix, plan.sprefix + plan.SM + 1, p.sprefix);
-    if (p.nsuper == 0) return hipSuccess;
     const int nblocks = plan.nblocks;
     constexpr size_t lds = (size_t)DMA_STAGES * DMA_STAGE_SLOTS * 16;
     static PerDeviceOnce once;
@@ -923,41 +936,32 @@ hipError_t launch_gemm_nt_dma(hipStream_t s, const GemmArgs& a) {
         return hipSuccess;
     });
     if (ea != hipSuccess) return ea;
-    const Tuning& tn = tuning();
     p.dbg = tn.gemm_dbg & 0xff;
     p.stamps = tn.gemm_stamps;
     p.slot = nullptr;
     p.nblocks = nblocks;
+    // ticket form (option gemm_ticket: 1 for the Cholesky's trailing updates while two streams are busy, 2 for every
+    // launch of at least one round; gemm_reserve CUs per XCD stay untouched)
+    if (ticket) {
+        const int reserve = std::max(0, std::min(tn.gemm_reserve, pool->groups / 8 - 1));
+        p.slot = pool->next();
+        const int groups = pool->groups - 8 * reserve;
+        constexpr size_t ldst = lds + 16;          // ring + mailbox
+        if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_ticket_kernel, dim3(groups), dim3(512), ldst, s, p);
+        else hipLaunchKernelGGL(gemm_nt_dma_ticket_kernel, dim3(groups), dim3(512), ldst, s, p);
+        return hipGetLastError();
+    }
     // persistent form: launches with at least two rounds of tiles and a K loop long enough to draw the successor in --
     // and the chip to themselves: resident workgroups (216 registers per lane, two waves per SIMD) leave no room on a
     // CU for the panel kernels of the other stream, which would then wait for the whole launch instead of a tile
-    // (lookahead with both forms: N = 16384 fit + predict 39.8 against 42.9 ms)
-    // ticket form (option gemm_ticket: 1 for the Cholesky's trailing updates while two streams are busy, 2 for every
-    // launch of at least one round; gemm_reserve CUs per XCD stay untouched)
-    if (tn.gemm_dma_waves == 8 && !p.dbg &&
-        (tn.gemm_ticket >= 2 || (tn.gemm_ticket == 1 && a.role == 1 && gemm_two_streams_active()))) {
-        PersistPool* pool = persist_pool();
-        const int reserve = std::max(0, std::min(tn.gemm_reserve, pool ? pool->groups / 8 - 1 : 0));
-        if (pool && nblocks >= pool->groups) {
-            p.slot = pool->next();
-            const int groups = pool->groups - 8 * reserve;
-            constexpr size_t ldst = lds + 16;          // ring + mailbox
-            if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_ticket_kernel, dim3(groups), dim3(512), ldst, s, p);
-            else hipLaunchKernelGGL(gemm_nt_dma_ticket_kernel, dim3(groups), dim3(512), ldst, s, p);
-            return hipGetLastError();
-        }
-    }
-    if (tn.gemm_persist && tn.gemm_dma_waves == 8 && !p.dbg && p.nchunks >= 16 && !gemm_two_streams_active()) {
-        // no pool (its allocation or the opt-in failed, or an unusual device): the persistent form is an optimisation,
-        // the per-tile launch below computes the same bits
-        PersistPool* pool = persist_pool();
-        if (pool && nblocks >= 2 * pool->groups) {
-            p.slot = pool->next();
-            constexpr size_t ldsp = lds + 16;          // ring + mailbox
-            if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);
-            else hipLaunchKernelGGL(gemm_nt_dma_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);
-            return hipGetLastError();
-        }
+    // (lookahead with both forms: N = 16384 fit + predict 39.8 against 42.9 ms).  No pool (its allocation or the opt-in
+    // failed, or an unusual device): the per-tile launch below computes the same bits.
+    if (persist) {
+        p.slot = pool->next();
+        constexpr size_t ldsp = lds + 16;          // ring + mailbox
+        if (a.role == 1) hipLaunchKernelGGL(chol_trailing_update_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);
+        else hipLaunchKernelGGL(gemm_nt_dma_persist_kernel, dim3(pool->groups), dim3(512), ldsp, s, p);
+        return hipGetLastError();
     }
     if (tn.gemm_dma_waves == 8) {
         if (p.dbg) hipLaunchKernelGGL((gemm_nt_dma_kernel<2, true>), dim3(nblocks), dim3(512), lds, s, p);

@@ -94,6 +94,8 @@ static int set_tuning_option(Tuning& t, const char* name, int64_t value) {
     } else if (!strcmp(name, "gemm_ticket")) {
         if (value < 0 || value > 2) return fail_arg("gemm_ticket must be 0 (off), 1 (trailing updates under lookahead) or 2 (every launch)");
         t.gemm_ticket = (int)value;
+    } else if (!strcmp(name, "gemm_balance")) {
+        t.gemm_balance = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_reserve")) {
         if (value < 0 || value > 24) return fail_arg("gemm_reserve must be in 0..24 (CUs per XCD)");
         t.gemm_reserve = (int)value;

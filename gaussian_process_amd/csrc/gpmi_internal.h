@@ -20,6 +20,7 @@ struct Tuning {
     int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
     int gemm_persist = 1;       // resident workgroups that chain the K loops of consecutive tiles (launches with >= 2 rounds of tiles)
     int gemm_ticket = 0;        // ticket form of the per-tile kernel (resident workgroups, tiles drawn from counters, no state across tiles): 1 Cholesky trailing updates under lookahead, 2 every launch of at least one round
+    int gemm_balance = 1;       // per-tile launches: choose the supertile edge of mid-size triangular launches by the deal of blocks to the XCDs (gpmi_plan.h: plan_tri_xcd_efficiency); 0: always the widest
     int gemm_reserve = 0;       // ticket form: CUs per XCD the launch leaves untouched (for the panel kernels of the other stream)
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
     int trsm_wave = 1;          // 1: wave-per-row substitution kernel for short panels, 0: lane-per-row always

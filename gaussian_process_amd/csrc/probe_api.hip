@@ -1,5 +1,7 @@
 // Measurement probes of the C-ABI (fp64 MFMA issue rate, GEMM kernel ablations, HBM store patterns):
 // what scripts/probe*.py and the numbers in DESIGN.md section 4 come from.  Not on the product path.
+#include <chrono>
+
 #include "gpmi_ctx.h"
 
 using namespace gpmi;
@@ -357,6 +359,37 @@ int gpmi_probe_launch_storm(gpmi_ctx* c, int high_priority, int count, double sl
     }
     (void)hipStreamDestroy(st);          // released when the kernels have finished
     if (e != hipSuccess) return fail_runtime(e, "probe_tiny launch");
+    return GPMI_OK;
+}
+
+// How many streams of a priority really run side by side?  n_high streams at the device's highest priority and n_norm at
+// the default one, each handed ONE one-wave kernel that sleeps `milliseconds`; *wall_ms = time until all have finished.
+// All concurrent: ~milliseconds; streams that share a hardware queue run one after the other: a multiple of it.  The
+// runtime maps streams onto a small pool of hardware queues as they are first used (a second
+// DistGP instance's fresh pair of auxiliary streams landed on one queue).
+int gpmi_probe_stream_overlap(gpmi_ctx* c, int n_high, int n_norm, double milliseconds, double* wall_ms) {
+    if (!c || !wall_ms || n_high < 0 || n_norm < 0 || n_high + n_norm < 1 || n_high + n_norm > 32 || !(milliseconds > 0.0) ||
+        milliseconds > 1000.0)
+        return fail_arg("gpmi_probe_stream_overlap: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    std::vector<hipStream_t> st((size_t)(n_high + n_norm), nullptr);
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < st.size() && e == hipSuccess; ++i)
+        e = hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, (int)i < n_high ? hi : lo);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < st.size() && e == hipSuccess; ++i) {
+        hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, st[i], (unsigned long long)(milliseconds * 1e5), 0,
+                           (unsigned long long*)nullptr);
+        e = hipGetLastError();
+    }
+    for (size_t i = 0; i < st.size(); ++i)
+        if (st[i]) { if (e == hipSuccess) e = hipStreamSynchronize(st[i]); }
+    *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (hipStream_t s : st) if (s) (void)hipStreamDestroy(s);
+    if (e != hipSuccess) return fail_runtime(e, "gpmi_probe_stream_overlap");
     return GPMI_OK;
 }
 

@@ -44,6 +44,7 @@ from . import _lib
 from ._lib import check
 
 YB = 128                  # rows of the y block (one tile)
+_SHARED_STREAMS = {}      # (device index, name, host thread) -> torch.cuda.Stream: see DistGP._named_stream
 INT64_MAX = (1 << 63) - 1
 
 
@@ -405,6 +406,8 @@ class DistGP:
         # -- measured on the 8-rank replay: the update itself runs 5-10 % faster, the panel solves that share the CUs with
         # the resident workgroups 2-3x slower, the step not faster (profiles/r04_replay_ticket_ab.txt): off by default
         self.ticket = int(os.environ.get("GPMI_DIST_TICKET", "0"))
+        if os.environ.get("GPMI_DIST_BALANCE") == "0" and hasattr(self.ops, "set_option"):     # A/B switch of the XCD-balanced launch geometry
+            self.ops.set_option("gemm_balance", 0)
         self.have_factor = False
         self._vinv_blocks = set()    # local diagonal blocks whose 128 x 128 inverses are in place (backward solve)
         self._vside = {}             # local diagonal block -> its inverses' side buffer (one-launch backward solve)
@@ -654,19 +657,24 @@ class DistGP:
         import contextlib
         if not self._cuda():
             return contextlib.nullcontext()
-        if getattr(self, "_side_stream", None) is None:
-            lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-            self._side_stream = torch.cuda.Stream(device=self.dev, priority=hi)
-        return torch.cuda.stream(self._side_stream)
+        return torch.cuda.stream(self._named_stream("side"))
 
     def _named_stream(self, name):
+        """The auxiliary streams ('side', 'crit') are ONE set per process and device, shared by every DistGP instance: the
+        runtime maps streams onto a small pool of hardware queues as they are first used, and a second instance's fresh
+        pair can land on ONE queue -- its panel chain and its diagonal-block chain then run one after the other instead
+        of side by side (measured on the 8-rank replay: the same rank 259 ms as the first instance of its process,
+        315 ms as the second; profiles/r04_stream_mapping.txt).  Ordering between instances is the streams' own."""
         if not self._cuda():
             return None
-        streams = self.__dict__.setdefault("_streams", {})
-        if name not in streams:
+        import threading
+        # (per host thread: the thread-rank tests run several ranks of one world in one process, each with streams of its own)
+        key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device(), name, threading.get_ident())
+        st = _SHARED_STREAMS.get(key)
+        if st is None:
             lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
-            streams[name] = torch.cuda.Stream(device=self.dev, priority=hi)
-        return streams[name]
+            st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=self.dev, priority=hi)
+        return st
 
     def _on(self, name):
         """context manager: run on the named auxiliary stream ('side', 'crit'); no-op on CPU"""

@@ -215,6 +215,10 @@ int gpmi_device_info(gpmi_ctx* ctx, double* out, int count);
  * m rows (trsm128); *out_us = microseconds per launch; stamps_out (64 entries or NULL) = in-kernel clock stamps
  * of one instrumented launch (layout: csrc/panel_mfma.hip) */
 int gpmi_probe_panel(gpmi_ctx* ctx, int kind, int64_t m, int reps, double* out_us, uint64_t* stamps_out);
+/* diagnostic: n_high streams at the highest priority + n_norm at the default one, one sleeping one-wave kernel of
+ * `milliseconds` on each; *wall_ms = time until all are done (about `milliseconds` when every stream has a hardware
+ * queue of its own, a multiple when streams share one) */
+int gpmi_probe_stream_overlap(gpmi_ctx* ctx, int n_high, int n_norm, double milliseconds, double* wall_ms);
 /* diagnostic: `count` one-wave kernels of sleep_us microseconds each on a stream of their own (high_priority != 0: the
  * device's highest priority), back to back; kind 0 sleep only, 1 + an agent-scope release / acquire fence pair, 2 + an
  * agent-scope atomic store.  Returns at once: time gpmi_probe_gemm meanwhile to see what a second stream's kernel

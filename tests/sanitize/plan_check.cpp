@@ -4,6 +4,7 @@
 //     offset, row maps with and without a host copy, ragged Tm / Tn, every supertile edge, M up to 131072);
 //   * a staircase with more supertile rows than the table holds falls back to the rectangle -- it never overruns;
 //   * block-width schedules cover the columns exactly; the flop counts agree with element-by-element sums.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -106,6 +107,27 @@ int main() {
         CHECK(plan_tiles(p, Tm, Tn, 0, 0, true, map.data(), (int)map.size(), 1, S), "plan");
         CHECK((SMrows <= DMA_MAX_SM) == (p.tri == 2), "SM=%ld tri=%d: the staircase must be used iff its table holds it", (long)SMrows, p.tri);
         tiles += check_plan(Tm, Tn, 0, 0, &map, true, 1, S); ++plans;
+    }
+    // the XCD-balance model behind the choice of the supertile edge: against a brute-force count, and the choice itself
+    for (int Tn : {8, 16, 32, 40, 64, 72, 96, 104, 112, 120, 128, 200, 256}) {
+        for (int S : {8, 4, 2, 1}) {
+            TilePlan p;
+            CHECK(plan_tiles(p, Tn + 1, Tn, 1, 0, false, nullptr, 0, 1, S), "plan");
+            long load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
+            for (int b = 0; b < p.nblocks; ++b) {
+                int ti, tj;
+                if (plan_block_to_tile(p, b, ti, tj) && plan_tile_live(p, ti, tj, nullptr)) { ++load[b & 7]; ++total; }
+            }
+            long rounds = 0;
+            for (long l : load) rounds = std::max(rounds, (l + 31) / 32);
+            const double eff = rounds ? (double)total / 256.0 / (double)rounds : 1.0;
+            CHECK(p.tri != 1 || fabs(eff - plan_tri_xcd_efficiency(Tn + 1, Tn, S)) < 1e-12, "efficiency model Tn=%d S=%d: %g vs %g", Tn, S, eff, plan_tri_xcd_efficiency(Tn + 1, Tn, S));
+        }
+        TilePlan p;
+        CHECK(plan_tiles(p, Tn + 1, Tn, 1, 0, false, nullptr, 0, 1), "plan");
+        double best = 0.0;
+        for (int S : {8, 4, 2}) if (S <= Tn) best = std::max(best, plan_tri_xcd_efficiency(Tn + 1, Tn, S));
+        CHECK(p.tri != 1 || p.S == 1 || plan_tri_xcd_efficiency(Tn + 1, Tn, p.S) >= best - 0.01 - 1e-12, "Tn=%d: chosen S=%d is not within 1 %% of the best deal", Tn, p.S);
     }
     // refused arguments
     { TilePlan p; CHECK(!plan_tiles(p, 0, 4, 0, 0, false, nullptr, 0, 1), "Tm = 0 accepted");
