@@ -684,9 +684,10 @@ int gpmi_lml_batch(gpmi_ctx* c, const double* triples, int64_t T, double* lml_ou
     if (!c->have_train) return fail_arg("gpmi_lml_batch: no training set (call gpmi_set_train)");
     HIP_TRY(hipSetDevice(c->device));
     const int64_t Np = round_up(c->N, TILE);
-    // two lanes; more do not help (measured, 12 triples: N = 512 0.45 / 0.24 / 0.38 / 0.31 ms per triple with
-    // 1 / 2 / 3 / 4 lanes, unchanged with GPU_MAX_HW_QUEUES=8)
-    int L = c->lanes ? c->lanes : (Np <= 32768 ? 2 : 1);
+    // two lanes; more do not help the small sizes (measured, 12 triples: N = 512 0.45 / 0.24 / 0.38 / 0.31 ms per triple with
+    // 1 / 2 / 3 / 4 lanes, unchanged with GPU_MAX_HW_QUEUES=8); three from the lookahead threshold up (N = 32768, round 4:
+    // 0.1934 / 0.1865 / 0.1849 / 0.1855 s per triple with 1 / 2 / 3 / 4 lanes, profiles/r04_cfg5_lanes.txt)
+    int L = c->lanes ? c->lanes : (Np > 32768 ? 1 : Np >= 12288 ? 3 : 2);
     L = (int)std::min<int64_t>(L, std::max<int64_t>(T, 1));
     while ((int)c->lane_ctx.size() < L - 1) {
         gpmi_ctx* l = nullptr;

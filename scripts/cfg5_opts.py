@@ -11,7 +11,7 @@ T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 X, y, _ = O.synthetic_problem(N, 8, 4)
 triples = np.array([[l, sf, s2] for l in (1., 2., 3., 4.) for sf in (.5, 1., 1.5, 2.) for s2 in (1e-4, 5e-4, 1e-3, 5e-3)])[:T]
 ref = None
-for lanes, la in ((2, 1), (1, 1), (2, 0), (3, 1), (3, 0), (4, 0)):
+for lanes, la in ((2, 1), (1, 1), (3, 1), (4, 1), (3, 0), (4, 0), (2, 1)):
     with GPContext(0) as ctx:
         ctx.set_option("lanes", lanes); ctx.set_option("lookahead", la)
         ctx.set_train(X, y)
