@@ -550,7 +550,13 @@ def main():
         pg_timeout = datetime.timedelta(seconds=float(os.environ.get("GPMI_BENCH_PG_TIMEOUT_S", "120")))
         wd.beat("init_process_group %s" % backend)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
+            # the process group's internal communication stream at high priority: its kernels (a few workgroups per channel)
+            # are placed ahead of the update's next tiles instead of taking turns with them
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=os.environ.get("GPMI_BENCH_NCCL_HIGH_PRIORITY", "1") == "1")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout, pg_options=opts)
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=pg_timeout)
         else:
             dist.init_process_group(backend, timeout=pg_timeout)
         wd.beat("process group up")

@@ -82,6 +82,11 @@ class ReplayComm:
         self._bidx = [torch.tensor(b, dtype=torch.int64, device=dev) for b in self._blocks]     # for gathers out of the source
         self._prep = None
         self.bytes = {"bcast": 0, "allgather": 0}      # what the absent ranks delivered, per kind
+        # null delivery (experiment, GPMI_REPLAY_NULL=1): the absent ranks' panel columns and diagonal blocks are NOT copied in
+        # -- the receive buffers keep whatever they held, results are garbage, and the timing is the rank's own work alone:
+        # the difference to a normal replay is what the replay's stand-in copies (15 GB read + written per fit) cost it
+        import os
+        self.null = os.environ.get("GPMI_REPLAY_NULL") == "1"
 
     # ---- the block ownership of dist.DistGP, for any rank q
     def _nblocks(self, q):
@@ -153,11 +158,15 @@ class ReplayComm:
         NB = s.NB
         if kind == "Lkk":
             k = tag[1]
+            if self.null:
+                return
             t.copy_(s.gp.A[k * NB:(k + 1) * NB, k * NB:(k + 1) * NB])
         elif kind == "m":
             t.copy_(s.gp.m)
         elif kind == "vblock":
             k = tag[1]
+            if self.null:
+                return
             t.copy_(s.gp.V[:, k * NB:(k + 1) * NB])
         else:
             raise NotImplementedError("ReplayComm.broadcast: no replay for %r" % (tag,))
@@ -180,7 +189,7 @@ class ReplayComm:
                     continue
                 if q == r:
                     O[q, :cnt].copy_(inp.view(cmax, NB, NB)[:cnt])
-                else:
+                elif not self.null:
                     ls = self._lstart(k, q)
                     torch.index_select(L3[:, :, k * NB:(k + 1) * NB], 0, self._bidx[q][ls:ls + cnt], out=O[q, :cnt])
                     self.bytes["allgather"] += cnt * NB * NB * 8
