@@ -1098,3 +1098,38 @@ def test_ticket_update_gemm_gives_the_same_bits(ctx, oracle, N, n, opts):
                 ctx.set_option(k, 0)
     assert out[0][0] == out[1][0]
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+def test_dev_sum_fixed_and_axpy2d_against_numpy():
+    """gpmi_dev_sum_fixed (the partitioned path's sums over gathered per-rank partials: GP_regression.py:140's right-hand
+    side m_k - sum_r part_r, tune_hyperparms_regression.py:312's log-determinant pieces) adds its contributions in index
+    order whatever the launch geometry -- bit-equal to the same loop in NumPy --, and gpmi_dev_axpy2d
+    (GP_regression.py:154: K_ss + jitter I - v^T v assembled from the all-reduced product) is one rounding per element"""
+    import torch
+    from gaussian_process_amd.dist import HipBlockOps
+    ops = HipBlockOps(0)
+    rng = np.random.default_rng(5)
+    for G, n, stride in ((8, 1024, 1024), (3, 700, 900), (1, 5, 5), (64, 1, 2)):
+        parts = rng.standard_normal(G * stride) * 10.0 ** rng.integers(-8, 8, G * stride)
+        base = rng.standard_normal(n)
+        pd, bd = torch.from_numpy(parts).cuda(), torch.from_numpy(base).cuda()
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        ops.sum_fixed(pd, G, stride, n, out, base=bd, scale=-1.0)
+        acc = np.zeros(n)
+        for q in range(G):
+            acc = acc + parts[q * stride:q * stride + n]
+        assert np.array_equal(out.cpu().numpy(), base + (-1.0) * acc)
+        ops.sum_fixed(pd, G, stride, n, out)                              # no base, scale 1
+        assert np.array_equal(out.cpu().numpy(), acc)
+        ops.sum_fixed(pd, G, stride, n, bd, base=bd, scale=-1.0)          # in place on the base
+        assert np.array_equal(bd.cpu().numpy(), base - acc)
+    Y = rng.standard_normal((300, 260))
+    X = rng.standard_normal((300, 256))
+    Yd, Xd = torch.from_numpy(Y).cuda(), torch.from_numpy(X).cuda()
+    ops.axpy2d(Yd[:, :256], Xd, 1.0)
+    want = Y.copy()
+    want[:, :256] += X
+    assert np.array_equal(Yd.cpu().numpy(), want)
+    ops.axpy2d(Yd[10:20, 3:7], Xd[10:20, 3:7], -2.5)
+    want[10:20, 3:7] += -2.5 * X[10:20, 3:7]
+    assert np.array_equal(Yd.cpu().numpy(), want)
