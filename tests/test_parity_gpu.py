@@ -1130,6 +1130,9 @@ def test_dev_sum_fixed_and_axpy2d_against_numpy():
     want = Y.copy()
     want[:, :256] += X
     assert np.array_equal(Yd.cpu().numpy(), want)
-    ops.axpy2d(Yd[10:20, 3:7], Xd[10:20, 3:7], -2.5)
-    want[10:20, 3:7] += -2.5 * X[10:20, 3:7]
+    ops.axpy2d(Yd[10:20, 3:7], Xd[10:20, 3:7], -1.0)
+    want[10:20, 3:7] -= X[10:20, 3:7]
     assert np.array_equal(Yd.cpu().numpy(), want)
+    ops.axpy2d(Yd[30:40, 100:104], Xd[30:40, 100:104], -2.5)              # a general factor: one or two roundings (fma)
+    want[30:40, 100:104] += -2.5 * X[30:40, 100:104]
+    assert np.allclose(Yd.cpu().numpy(), want, rtol=4e-16, atol=1e-300)
