@@ -608,6 +608,29 @@ def main():
 
     for k in range(args.warmup):
         step(k - args.warmup)
+    # Multi-rank: which form of a rank's large update launches?  One workgroup per tile loses 12 % for every shader engine in
+    # which another kernel holds a CU exclusively (LAB_NOTES.md: per-tile launches are dealt statically down to the engine);
+    # the ticket form loses only the CU's share but slows the panel solves that share CUs with it.  Whether RCCL's kernels
+    # hold CUs exclusively beside an update workgroup cannot be known on a one-GPU box, so it is MEASURED here, before the
+    # timed region: two untimed steps in each form, the maximum over ranks decides, every rank takes the same form.
+    update_form = None
+    if multi and world > 1 and os.environ.get("GPMI_DIST_TICKET", "auto") == "auto" and backend != "gloo":
+        trial = {}
+        for form in (0, 1):
+            gp.ticket = form
+            step(-1)
+            barrier()
+            tt = time.perf_counter()
+            step(-1)
+            step(-1)
+            barrier()
+            t = torch.tensor([(time.perf_counter() - tt) / 2], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            trial[form] = float(t.item())
+        gp.ticket = 1 if trial[1] < 0.98 * trial[0] else 0
+        update_form = {"chosen": "ticket" if gp.ticket else "per-tile", "per_tile_ms": trial[0] * 1e3, "ticket_ms": trial[1] * 1e3,
+                       "how": "two untimed steps in each form before the timed region, maximum over ranks; ticket needs 2 % to win"}
+        wd.beat("update form: %s" % update_form["chosen"])
     stage = {}
     barrier()
     t0 = time.perf_counter()
@@ -678,6 +701,7 @@ def main():
             out["backend"] = backend
             out["config"]["block_rows"] = nb_used
             out["config"]["row_block_layout"] = gp.layout
+            out["config"]["update_form"] = update_form if update_form is not None else ("ticket" if gp.ticket else "per-tile")
             out["stages_ms"] = stage            # last step, rank 0: fit / alpha / predict wall
             out["per_rank_ms"] = per_rank
             out["per_rank_diag"] = diag_all

@@ -70,6 +70,7 @@ SIGNATURES = {
     "gpmi_probe_hbm_ex": [_vp, _i64, C.c_int, C.c_int, _dp],
     "gpmi_device_info": [_vp, _dp, C.c_int],
     "gpmi_probe_panel": [_vp, C.c_int, _i64, C.c_int, _dp, C.POINTER(C.c_uint64)],
+    "gpmi_probe_gemm_beside_server": [_vp, _i64, _i64, _i64, C.c_int, C.c_int, C.c_int, C.c_int, _dp],
     "gpmi_probe_stream_overlap": [_vp, C.c_int, C.c_int, C.c_double, _dp],
     "gpmi_probe_launch_storm": [_vp, C.c_int, C.c_int, C.c_double, C.c_int],
     "gpmi_probe_trsv_giveup": [_vp, _i64, C.c_double, C.POINTER(C.c_int), _dp, _dp],

@@ -134,6 +134,29 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     const bool col_on_panel = la && ncols < 49152;
     const int slot_p = account ? GPMI_T_CHOL_PANEL : GPMI_T_COUNT - 1;
     const int slot_t = account ? GPMI_T_CHOL_TRAIL : GPMI_T_COUNT - 1;
+    // experiment (option potrf_server): the potrf128 of every leaf goes to ONE resident workgroup on a stream of its own
+    // (panel_mfma.hip), so that it never waits for an empty CU beside the update; the scope stops the server on every
+    // way out of this function
+    struct ServerScope {
+        gpmi_ctx* c; hipStream_t sp; bool on = false;
+        ~ServerScope() { if (on) (void)potrf_server_stop(&c->pserver, sp); }
+    } server{c, sp_};
+    if (la && tuning().potrf_server && tuning().panel_fused) {
+        if (!c->pmail.p) {
+            if ((e = c->pmail.ensure(sizeof(PotrfMail))) != hipSuccess) return e;
+            if ((e = hipMemset(c->pmail.p, 0, sizeof(PotrfMail))) != hipSuccess) return e;
+            c->pserver.mail = c->pmail.as<PotrfMail>();
+        }
+        if (!c->sstream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            // ablation 128: the server's stream at the default priority
+            if ((e = hipStreamCreateWithPriority(&c->sstream, hipStreamNonBlocking, (tuning().potrf_server & 128) ? lo : hi)) != hipSuccess) return e;
+        }
+        c->pserver.mode = tuning().potrf_server;
+        if ((e = potrf_server_start(&c->pserver, c->sstream)) != hipSuccess) return e;
+        server.on = true;
+    }
     if (la && (e = c->order(sm, sp_)) != hipSuccess) return e;   // panel 0 after the K build
     // `counted`: the launch enters the roofline figures (GPMI_T_CHOL_TRAIL, its own kernel symbol).  Under lookahead
     // only (b) does: (a) runs at the same time on the other stream, so summing both durations would count that
@@ -270,6 +293,16 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof info, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->timers_collect();
+    if (c->pserver.mail) {                  // the resident potrf128 server (experiment): a wait that gave up is an error, not a result
+        HIP_TRY(hipStreamSynchronize(c->pstream));
+        if (c->sstream) HIP_TRY(hipStreamSynchronize(c->sstream));
+        int perr = 0;
+        HIP_TRY(hipMemcpy(&perr, &c->pserver.mail->err, sizeof(int), hipMemcpyDeviceToHost));
+        if (perr) {
+            (void)hipMemset(&c->pserver.mail->err, 0, sizeof(int));
+            return fail_runtime(hipErrorUnknown, "gpmi_factorize: the resident potrf128 server did not answer (option potrf_server)");
+        }
+    }
     if (info != big && info < c->N) {
         if (bad_pivot) *bad_pivot = info + 1;
         if (lml) *lml = std::numeric_limits<double>::quiet_NaN();

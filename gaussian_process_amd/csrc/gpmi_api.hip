@@ -72,11 +72,12 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->X, &c->y, &c->A, &c->info, &c->red, &c->Xs, &c->V, &c->P, &c->vec, &c->dense,
-                       &c->U, &c->Kn, &c->gpart, &c->cov_a, &c->cov_b, &c->cov_out, &c->flag, &c->vside})
+                       &c->U, &c->Kn, &c->gpart, &c->cov_a, &c->cov_b, &c->cov_out, &c->flag, &c->vside, &c->pmail})
         b->release();
     for (auto e : c->ev_pool) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->pstream);
+    if (c->sstream) (void)hipStreamDestroy(c->sstream);
     delete c;
     return GPMI_OK;
 }
@@ -94,6 +95,9 @@ static int set_tuning_option(Tuning& t, const char* name, int64_t value) {
     } else if (!strcmp(name, "gemm_ticket")) {
         if (value < 0 || value > 2) return fail_arg("gemm_ticket must be 0 (off), 1 (trailing updates under lookahead) or 2 (every launch)");
         t.gemm_ticket = (int)value;
+    } else if (!strcmp(name, "potrf_server")) {
+        if (value < 0 || value > 1023) return fail_arg("potrf_server: 0 off, 1 on, bits 2..512 timing-only ablations");
+        t.potrf_server = (int)value;
     } else if (!strcmp(name, "gemm_balance")) {
         t.gemm_balance = value ? 1 : 0;
     } else if (!strcmp(name, "gemm_reserve")) {

@@ -93,6 +93,9 @@ struct gpmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // main stream: K build, trailing updates, reductions
     hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
+    hipStream_t sstream = nullptr;   // experiment (option potrf_server): the stream the resident potrf128 workgroup lives on
+    gpmi::PotrfServerState pserver;  // its mailbox and sequence numbers
+    DevBuf pmail;
     // options
     int64_t nb = 0;         // outer block width of the Cholesky (multiple of 128); 0 = by size
     int64_t block(int64_t ncols) const { return nb ? nb : (ncols >= 32768 ? 2048 : ncols >= 12288 ? 1024 : 512); }

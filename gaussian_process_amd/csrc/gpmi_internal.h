@@ -20,6 +20,7 @@ struct Tuning {
     int gemm_small_tiles = 1;   // 64 x 64 tiles for launches with few tiles
     int gemm_persist = 1;       // resident workgroups that chain the K loops of consecutive tiles (launches with >= 2 rounds of tiles)
     int gemm_ticket = 0;        // ticket form of the per-tile kernel (resident workgroups, tiles drawn from counters, no state across tiles): 1 Cholesky trailing updates under lookahead, 2 every launch of at least one round
+    int potrf_server = 0;       // experiment: potrf128 as a resident workgroup fed through a mailbox while a factorisation runs under lookahead
     int gemm_balance = 1;       // per-tile launches: choose the supertile edge of mid-size triangular launches by the deal of blocks to the XCDs (gpmi_plan.h: plan_tri_xcd_efficiency); 0: always the widest
     int gemm_reserve = 0;       // ticket form: CUs per XCD the launch leaves untouched (for the panel kernels of the other stream)
     int gemm_dma_waves = 8;     // 4: one wave per SIMD, 8: two waves per SIMD (32 x 64 per wave)
@@ -119,6 +120,24 @@ hipError_t launch_trsm_rlt64(hipStream_t s, const double* L, int64_t ldl, double
 // ---- panel_mfma.hip --------------------------------------------------------
 // Cholesky of one 128 x 128 diagonal block in place (lower), one workgroup, MFMA updates.
 hipError_t launch_potrf128(hipStream_t s, double* A, int64_t ld, int64_t col_offset, int64_t* info_dev);
+
+// potrf128 as a resident server (experiment; panel_mfma.hip): device mailbox + host-side state of one factorisation
+struct PotrfMail {
+    unsigned long long seq_post, seq_done;
+    unsigned long long A, ld, col_offset, info, quit;
+    int err;
+    int pad;
+};
+struct PotrfServerState {
+    PotrfMail* mail = nullptr;          // device, zero-initialised once
+    unsigned long long seq = 0;         // last sequence number handed out
+    unsigned long long first_seq = 0;
+    double idle_ms = 3000.0;            // the server leaves when nothing has come for this long
+    double wait_ms = 2000.0;            // a post gives up (sticky) after this long
+    int mode = 1;                       // the option's value: 1 on; further bits = timing-only ablations (panel_mfma.hip)
+};
+hipError_t potrf_server_start(PotrfServerState* st, hipStream_t server_stream);
+hipError_t potrf_server_stop(PotrfServerState* st, hipStream_t panel_stream);
 
 // X (m x 128) <- X * L^-T, L 128 x 128 lower; m multiple of 128; on the matrix pipe.
 hipError_t launch_trsm128(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m);

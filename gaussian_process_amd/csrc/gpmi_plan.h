@@ -66,6 +66,19 @@ GPMI_HD bool plan_block_to_tile(const PT& p, int b, int& ti, int& tj) {
         sj += si % p.SN;
         if (sj >= p.SN) sj -= p.SN;
     }
+    if (p.tri == 1 && si == sj) {
+        // A supertile ON the diagonal holds S (S + 1) / 2 live tiles.  They are enumerated FIRST, in row-major order of the
+        // lower triangle, the dead blocks after them: inside an XCD consecutive blocks go to its four shader engines in
+        // turn (gpmi_plan.h: plan_xcd_efficiency), and with the square enumeration the engine that gets tile columns 0 and
+        // 4 of every diagonal supertile carried 12 live tiles where the one with columns 3 and 7 carried 6.
+        int r = (int)((sqrtf(8.f * (float)q + 1.f) - 1.f) * 0.5f);
+        while ((r + 1) * (r + 2) / 2 <= q) ++r;
+        while (r * (r + 1) / 2 > q) --r;
+        if (r >= p.S) return false;
+        ti = si * p.S + r;
+        tj = sj * p.S + (q - r * (r + 1) / 2);
+        return ti < p.Tm && tj < p.Tn;
+    }
     ti = si * p.S + (q >> p.logS);
     tj = sj * p.S + (q & (p.S - 1));
     return ti < p.Tm && tj < p.Tn;
@@ -86,34 +99,16 @@ GPMI_HD bool plan_tile_live(const PT& p, int ti, int tj, const int32_t* row_ncol
     return true;
 }
 
-// The hardware deals workgroups to the 8 XCDs round-robin and an XCD works through its share on its own CUs, so a launch
-// takes as long as the XCD with the most live tiles: max_x ceil(load_x / CUs per XCD) rounds.  For a lower-triangular
-// launch enumerated in S x S supertiles (supertile s on XCD s % 8) this returns (total live tiles / 8) / max_x load_x
-// rounded to whole rounds -- 1.0 = every XCD ends in the same round.  Large launches sit at 0.98-1.0 with S = 8; a
-// launch of 30 .. 120 tile rows (the trailing updates of N = 16384, the last steps of every factorisation) at 0.55-0.93,
-// because a handful of supertiles per XCD cannot come out even -- and at 0.92-0.99 with S = 4.
-inline double plan_tri_xcd_efficiency(int Tm, int Tn, int S, int cus_per_xcd = 32) {
-    const int SM = (Tm + S - 1) / S;
-    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long total = 0;
-    int s = 0;
-    for (int si = 0; si < SM; ++si)
-        for (int sj = 0; sj <= si; ++sj, ++s) {
-            long cnt = 0;
-            for (int a = 0; a < S; ++a) {
-                const int ti = si * S + a;
-                if (ti >= Tm) break;
-                const int c0 = sj * S, c1 = std::min(std::min((sj + 1) * S, Tn), ti + 1);      // live: tj <= ti
-                if (c1 > c0) cnt += c1 - c0;
-            }
-            load[s & 7] += cnt;
-            total += cnt;
-        }
-    long rounds = 0;
-    for (int x = 0; x < 8; ++x) rounds = std::max(rounds, (load[x] + cus_per_xcd - 1) / cus_per_xcd);
-    return rounds ? (double)total / (8.0 * cus_per_xcd) / (double)rounds : 1.0;
-}
-
+// How a launch of one workgroup per tile is dealt out (measured, round 4: profiles/r04_resident_cost_count.txt): block b
+// goes to XCD b % 8, and inside the XCD consecutive blocks go to its four shader engines in turn -- engine ((b >> 3) % 4) --,
+// each of which places them on its own 8 CUs as they become free.  Nothing is balanced ACROSS engines: the launch lasts as
+// long as the engine with the most live tiles needs, in whole rounds of 8 (one CU held by another kernel costs a per-tile
+// launch 12 %, two in one engine 27 %, three 40 %: 8/7, 8/6, 8/5 -- while a resident form that draws tiles from counters
+// loses the CUs' share, 0.4 % each).  plan_xcd_efficiency walks a plan's blocks and returns
+//     (live tiles / 256) / max over the 32 engines of ceil(live tiles of the engine / 8):
+// 1.0 = every engine ends in the same round.  With 8 x 8 supertiles enumerated as squares a lower-triangular launch of 496
+// tile rows sits at 0.991, of 112 rows at 0.898, of 64 at 0.838; with the diagonal supertiles' live tiles first and the edge
+// chosen by this figure at 0.997 / 0.968 / 0.931.
 // Plan a launch over Tm x Tn tiles.  row_ncols_host / row_bands: host copy of the row map (null: none known on the
 // host); has_row_map: the launch has a device row map (with or without a host copy).  force_S != 0 pins the supertile
 // edge (tests).  balance_xcds: the launch is one workgroup per tile, dealt statically to the XCDs -- pick the supertile
@@ -123,17 +118,17 @@ inline bool plan_tiles(TilePlan& p, int64_t Tm, int64_t Tn, int lower, int64_t d
                        const int32_t* row_ncols_host, int row_bands, int row_block_tiles, int force_S = 0,
                        bool balance_xcds = true);
 
-// the same figure for ANY plan, by walking its blocks (host; O(blocks)): live tiles per XCD group -> whole rounds
-inline double plan_xcd_efficiency(const TilePlan& p, const int32_t* row_ncols_host, int cus_per_xcd = 32) {
-    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+inline double plan_xcd_efficiency(const TilePlan& p, const int32_t* row_ncols_host, int cus_per_engine = 8) {
+    long load[32];
+    for (int x = 0; x < 32; ++x) load[x] = 0;
     long total = 0;
     for (int b = 0; b < p.nblocks; ++b) {
         int ti, tj;
-        if (plan_block_to_tile(p, b, ti, tj) && plan_tile_live(p, ti, tj, row_ncols_host)) { ++load[b & 7]; ++total; }
+        if (plan_block_to_tile(p, b, ti, tj) && plan_tile_live(p, ti, tj, row_ncols_host)) { ++load[b & 31]; ++total; }
     }
     long rounds = 0;
-    for (int x = 0; x < 8; ++x) rounds = std::max(rounds, (load[x] + cus_per_xcd - 1) / cus_per_xcd);
-    return rounds ? (double)total / (8.0 * cus_per_xcd) / (double)rounds : 1.0;
+    for (int x = 0; x < 32; ++x) rounds = std::max(rounds, (load[x] + cus_per_engine - 1) / cus_per_engine);
+    return rounds ? (double)total / (32.0 * cus_per_engine) / (double)rounds : 1.0;
 }
 
 inline bool plan_tiles(TilePlan& p, int64_t Tm, int64_t Tn, int lower, int64_t diag_off, bool has_row_map,
@@ -154,21 +149,17 @@ inline bool plan_tiles(TilePlan& p, int64_t Tm, int64_t Tn, int lower, int64_t d
     while (S > 1 && (S > p.Tn || S > p.Tm)) S >>= 1;
     // mid-size triangular launches: the largest supertile edge whose deal to the XCDs is within 1 % of the best one
     // (plan_tri_xcd_efficiency); never below 2 (an edge of 1 gives up all reuse of the operands in an XCD's L2)
-    if (!force_S && balance_xcds && p.tri == 1 && !stairs && p.Tn <= 256 && S > 2) {
-        double best = 0.0;
-        for (int c = S; c >= 2; c >>= 1) best = std::max(best, plan_tri_xcd_efficiency(p.Tm, p.Tn, c));
-        for (int c = S; c >= 2; c >>= 1)
-            if (plan_tri_xcd_efficiency(p.Tm, p.Tn, c) >= best - 0.01) { S = c; break; }
-    }
-    // a rank's staircase of row blocks (row map with a host copy): the same choice, by walking each candidate's blocks --
-    // for launches small enough that a supertile more or less on one XCD shows (up to 16384 tiles: 64 rounds)
-    if (!force_S && balance_xcds && stairs && S > 2 && (int64_t)p.Tm * p.Tn <= 16384) {
+    // a rank's staircase of row blocks (row map with a host copy) and mid-size triangular launches: the widest edge whose
+    // deal is within 1 % of the best, by walking each candidate's blocks -- for launches small enough that a supertile more
+    // or less on one engine shows (up to 256 tile columns of a triangle, 16384 tiles of a staircase)
+    if (!force_S && balance_xcds && S > 2 &&
+        ((p.tri == 1 && !stairs && p.Tn <= 256) || (stairs && (int64_t)p.Tm * p.Tn <= 16384))) {
         double eff[4] = {0., 0., 0., 0.}, best = 0.0;
         int cand[4], nc = 0;
         for (int c = S; c >= 2 && nc < 4; c >>= 1) {
             TilePlan q;
             if (!plan_tiles(q, Tm, Tn, lower, diag_off, has_row_map, row_ncols_host, row_bands, row_block_tiles, c, false)) break;
-            if (q.tri != 2) break;                       // the staircase table does not hold this edge
+            if (stairs && q.tri != 2) break;             // the staircase table does not hold this edge
             cand[nc] = c;
             eff[nc] = plan_xcd_efficiency(q, row_ncols_host);
             best = std::max(best, eff[nc]);

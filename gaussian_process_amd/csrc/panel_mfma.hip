@@ -243,9 +243,8 @@ __device__ __forceinline__ void stage_w_tile(const double* Ljj, int64_t ldl, d2*
 // factors so much slower on SIMDs shared with the update's MFMA stream that the panel stream gets longer (DESIGN.md
 // section 7 item 2).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, int64_t col_offset, int64_t* info,
-                                                        unsigned long long* stamps) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void potrf128_body(double* A, int64_t ld, int64_t col_offset, int64_t* info,
+                                              unsigned long long* stamps, char* smem) {
     d2* tiles = reinterpret_cast<d2*>(smem);          // slot i: -L_ij of the current step j (block row i), slot 8: W_jj
     double* scratch = reinterpret_cast<double*>(smem + POTRF_TILES * TILE_BYTES);    // 16 x SCR_LD doubles
     const int lane = threadIdx.x & 63;
@@ -303,6 +302,130 @@ __global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, in
         PANEL_STAMP(wave == (j < 7 ? j + 1 : 7), 6 * j + 5);
     }
     PANEL_STAMP(wave == 7, 49);
+#undef PANEL_STAMP
+}
+
+__global__ __launch_bounds__(512) void potrf128_kernel(double* A, int64_t ld, int64_t col_offset, int64_t* info,
+                                                        unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    potrf128_body(A, ld, col_offset, info, stamps, smem);
+}
+
+// ---------------------------------------------------------------------------
+// potrf128 as a SERVER (experiment, option potrf_server): one workgroup stays on a CU for a whole factorisation and factors
+// the 128 x 128 diagonal blocks it is handed through a mailbox, so that no potrf128 launch has to wait for the trailing
+// update's next round boundary to find an empty CU (a kernel of 8 waves x 123 registers does not fit beside an update
+// workgroup).  In the panel stream the launch of potrf128 becomes the launch of a one-wave "post" kernel that writes the
+// job (agent-scope atomic stores), bumps the sequence number and WAITS for the server's answer -- the stream's order does
+// the rest: the kernels behind it start when the block is factored.  Visibility: the block was written by kernels that
+// finished before the post started (their end-of-kernel release); the server takes an agent-scope acquire fence before it
+// reads (it has no kernel boundary of its own) and a release fence before it answers.  Every wait is bounded by wall time
+// and a give-up is sticky (PotrfMail::err), so a server that never started costs ONE bound, not one per leaf.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mail_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void mail_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// `mode` (ablations of the experiment; results are only right for mode 1): 2 no acquire / release fences in the server,
+// 4 the post does not wait for the answer, 8 the server is resident but never used (plain potrf128 launches),
+// 16 the server polls once per ~0.2 ms, 32 the server answers without doing the work
+__global__ __launch_bounds__(512) void potrf128_server_kernel(PotrfMail* m, unsigned long long first_seq,
+                                                               unsigned long long idle_ticks, int mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile unsigned long long* job = reinterpret_cast<volatile unsigned long long*>(smem + POTRF_TILES * TILE_BYTES + 16 * SCR_LD * 8);
+    unsigned long long seen = first_seq - 1;
+    // ablations 256 / 512 (with 8, the server is never used): waves 1-7 leave at once / wait for wave 0 by polling an LDS
+    // word with s_sleep between reads instead of sitting at the workgroup barrier
+    if ((mode & 256) && threadIdx.x >= 64) return;
+    volatile unsigned long long* go = job + 6;
+    if (threadIdx.x == 0) *go = 0;
+    __syncthreads();
+    unsigned long long round = 0;
+    for (;;) {
+        ++round;
+        if ((mode & 512) && threadIdx.x >= 64) {
+            while (*go < round) __builtin_amdgcn_s_sleep(64);
+        }
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long sq = mail_load(&m->seq_post);
+            int polls = 0;
+            while (sq <= seen || sq < first_seq) {
+                if (mode & 16) { for (int q = 0; q < 64; ++q) __builtin_amdgcn_s_sleep(127); }      // ~one poll per 0.2 ms
+                else __builtin_amdgcn_s_sleep(2);
+                sq = mail_load(&m->seq_post);
+                if ((++polls & 255) == 0 && wall_clock64() - t0 > idle_ticks) { sq = ~0ull; break; }
+            }
+            job[0] = sq;
+            if (sq != ~0ull) {
+                job[1] = mail_load(&m->A);
+                job[2] = mail_load(&m->ld);
+                job[3] = mail_load(&m->col_offset);
+                job[4] = mail_load(&m->info);
+                job[5] = mail_load(&m->quit);
+            }
+            *go = round;
+        }
+        __syncthreads();
+        const unsigned long long sq = job[0];
+        if (sq == ~0ull) {                                   // nothing came for idle_ticks: leave (a post that comes later gives up)
+            if (threadIdx.x == 0) { int* e = &m->err; __hip_atomic_store(e, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            return;
+        }
+        double* A = reinterpret_cast<double*>(job[1]);
+        const int64_t ld = (int64_t)job[2], col = (int64_t)job[3];
+        int64_t* info = reinterpret_cast<int64_t*>(job[4]);
+        const bool quit = job[5] != 0;
+        __syncthreads();                                      // job[] is rewritten by thread 0 in the next round
+        if (!quit && !(mode & 32)) {
+            if (!(mode & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            potrf128_body(A, ld, col, info, nullptr, smem);
+            if (!(mode & 2)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) mail_store(&m->seq_done, sq);
+        if (quit) return;
+        seen = sq;
+    }
+}
+
+// ablation 64: in place of the server, ONE wave that only waits for the quit message (no registers to speak of, no LDS)
+__global__ __launch_bounds__(64) void potrf128_idle_kernel(PotrfMail* m, unsigned long long first_seq, unsigned long long idle_ticks) {
+    if (threadIdx.x) return;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long sq = mail_load(&m->seq_post);
+        if (sq >= first_seq && mail_load(&m->quit)) { mail_store(&m->seq_done, sq); return; }
+        for (int q = 0; q < 16; ++q) __builtin_amdgcn_s_sleep(127);
+        if (wall_clock64() - t0 > 10 * idle_ticks) return;
+    }
+}
+
+__global__ __launch_bounds__(64) void potrf128_post_kernel(PotrfMail* m, unsigned long long seq, double* A, int64_t ld,
+                                                            int64_t col_offset, int64_t* info, int quit,
+                                                            unsigned long long wait_ticks, int mode) {
+    if (threadIdx.x) return;
+    if (__hip_atomic_load(&m->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;       // a wait has given up before: do not wait again
+    mail_store(&m->A, (unsigned long long)reinterpret_cast<uintptr_t>(A));
+    mail_store(&m->ld, (unsigned long long)ld);
+    mail_store(&m->col_offset, (unsigned long long)col_offset);
+    mail_store(&m->info, (unsigned long long)reinterpret_cast<uintptr_t>(info));
+    mail_store(&m->quit, (unsigned long long)quit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // the job's fields before its number
+    mail_store(&m->seq_post, seq);
+    if ((mode & 4) && !quit) return;
+    const unsigned long long t0 = wall_clock64();
+    int polls = 0;
+    while (mail_load(&m->seq_done) < seq) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++polls & 255) == 0 && wall_clock64() - t0 > wait_ticks) {
+            __hip_atomic_store(&m->err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -567,10 +690,45 @@ static hipError_t panel_mfma_attrs() {
     });
 }
 
+// the server a factorisation on this thread has started (PotrfServerScope), or null
+static thread_local PotrfServerState* t_potrf_server = nullptr;
+
+hipError_t potrf_server_start(PotrfServerState* st, hipStream_t server_stream) {
+    if (!st || !st->mail) return hipErrorInvalidValue;
+    hipError_t e = panel_mfma_attrs();
+    if (e != hipSuccess) return e;
+    st->first_seq = ++st->seq;                      // the first job of this server's life
+    --st->seq;
+    if (st->mode & 64)
+        hipLaunchKernelGGL(potrf128_idle_kernel, dim3(1), dim3(64), 0, server_stream, st->mail, st->seq + 1,
+                           (unsigned long long)(st->idle_ms * 1e5));
+    else
+        hipLaunchKernelGGL(potrf128_server_kernel, dim3(1), dim3(512), POTRF_TILES * TILE_BYTES + 16 * SCR_LD * 8 + 64, server_stream,
+                           st->mail, st->seq + 1, (unsigned long long)(st->idle_ms * 1e5), st->mode);
+    e = hipGetLastError();
+    if (e == hipSuccess) t_potrf_server = st;
+    return e;
+}
+
+hipError_t potrf_server_stop(PotrfServerState* st, hipStream_t s) {
+    t_potrf_server = nullptr;
+    if (!st || !st->mail) return hipSuccess;
+    hipLaunchKernelGGL(potrf128_post_kernel, dim3(1), dim3(64), 0, s, st->mail, ++st->seq, (double*)nullptr, (int64_t)0, (int64_t)0,
+                       (int64_t*)nullptr, 1, (unsigned long long)(st->wait_ms * 1e5), st->mode);
+    return hipGetLastError();
+}
+
 hipError_t launch_potrf128(hipStream_t s, double* A, int64_t ld, int64_t col_offset, int64_t* info_dev) {
     if (ld % 2 || (reinterpret_cast<uintptr_t>(A) & 15)) return hipErrorInvalidValue;
     hipError_t e = panel_mfma_attrs();
     if (e != hipSuccess) return e;
+    PotrfServerState* st = t_potrf_server;
+    if (st && !(st->mode & 8)) {                     // hand the block to the resident workgroup and wait for it in stream order
+        hipLaunchKernelGGL(potrf128_post_kernel, dim3(1), dim3(64), 0, s, st->mail, ++st->seq, A, ld, col_offset, info_dev, 0,
+                           (unsigned long long)(st->wait_ms * 1e5), st->mode);
+        if (!(st->mode & 4)) return hipGetLastError();
+        // mode 4 (the post does not wait): the plain launch below does the work, the server does it too, unordered
+    }
     hipLaunchKernelGGL(potrf128_kernel, dim3(1), dim3(512), POTRF_TILES * TILE_BYTES + 16 * SCR_LD * 8, s, A, ld, col_offset,
                        info_dev, tuning().panel_stamps);
     return hipGetLastError();

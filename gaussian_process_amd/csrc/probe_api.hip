@@ -54,6 +54,17 @@ int gpmi_probe_mfma_f64(gpmi_ctx* c, double* tflops) {
 // variant: ablation bits (1: no global loads in the K loop, 2: no LDS writes / barriers,
 // 4: epilogue without the C read, 8: no epilogue).  out[0] = TFLOP/s over computed tiles,
 // out[1] = ms per launch.
+// pseudo-random operands in (-1, 1) (variant bit 32 of gpmi_probe_gemm): constant operands keep the matrix pipe's data
+// paths from toggling, and a chip that is not at its power limit hides what a power-limited one shows
+__global__ void probe_fill_random_kernel(double* A, int64_t ld, int64_t ncols, unsigned long long seed) {
+    double* row = A + (int64_t)blockIdx.y * ld;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < ncols; j += (int64_t)gridDim.x * blockDim.x) {
+        unsigned long long x = seed + (unsigned long long)blockIdx.y * 0x9E3779B97F4A7C15ull + (unsigned long long)j * 0xBF58476D1CE4E5B9ull;
+        x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+        row[j] = (double)(long long)(x >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+    }
+}
+
 int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps,
                     double* out) {
     if (!c || !out) return fail_arg("gpmi_probe_gemm: null argument");
@@ -72,8 +83,15 @@ int gpmi_probe_gemm(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int
         if ((e = C.ensure((size_t)M * ldc * 8)) != hipSuccess || (e = A.ensure((size_t)M * ldk * 8)) != hipSuccess ||
             (e = B.ensure((size_t)N * ldk * 8)) != hipSuccess) { rc = fail_runtime(e, "hipMalloc"); break; }
         (void)hipMemsetAsync(C.p, 0, (size_t)M * ldc * 8, s);
-        (void)launch_fill_rows(s, A.as<double>(), ldk, M, K, 0.001);
-        (void)launch_fill_rows(s, B.as<double>(), ldk, N, K, -0.002);
+        if (variant & 32) {
+            hipLaunchKernelGGL(probe_fill_random_kernel, dim3(8, (unsigned)M), dim3(256), 0, s, A.as<double>(), ldk, K, 0x1234ull);
+            hipLaunchKernelGGL(probe_fill_random_kernel, dim3(8, (unsigned)N), dim3(256), 0, s, B.as<double>(), ldk, K, 0x9876ull);
+            hipLaunchKernelGGL(probe_fill_random_kernel, dim3(64, (unsigned)M), dim3(256), 0, s, C.as<double>(), ldc, N, 0x5555ull);
+            variant &= ~32;
+        } else {
+            (void)launch_fill_rows(s, A.as<double>(), ldk, M, K, 0.001);
+            (void)launch_fill_rows(s, B.as<double>(), ldk, N, K, -0.002);
+        }
         GemmArgs g;
         g.C = C.as<double>(); g.A = A.as<double>(); g.B = B.as<double>();
         g.ldc = ldc; g.lda = g.ldb = ldk; g.M = M; g.N = N; g.K = K; g.mode = 0; g.lower = lower; g.diag_off = 0;
@@ -281,8 +299,10 @@ __global__ void probe_sleeper_kernel(unsigned long long ticks, const unsigned lo
         return;
     }
     // the way a flag-chained resident kernel waits: thread 0 re-reads a device flag with agent-scope atomic loads
-    // (poll_sleep = argument of s_sleep between two reads); fences != 0: an agent-scope acquire + release pair every
-    // ~30 us, as a kernel would issue around each unit of work it is released for
+    // (poll_sleep = argument of s_sleep between two reads); fences & 1: an agent-scope acquire + release pair every
+    // ~30 us, as a kernel would issue around each unit of work it is released for; fences & 2: the OTHER waves of the
+    // workgroup do not leave but wait at a workgroup barrier for thread 0 (as the waves of a server workgroup wait for
+    // their next job) -- round 4: THAT is what costs a concurrent GEMM 14 %
     if (threadIdx.x == 0) {
         unsigned long long acc = 0, last = t0;
         while (wall_clock64() - t0 < ticks) {
@@ -291,7 +311,7 @@ __global__ void probe_sleeper_kernel(unsigned long long ticks, const unsigned lo
             else if (poll_sleep <= 2) __builtin_amdgcn_s_sleep(2);
             else if (poll_sleep <= 16) __builtin_amdgcn_s_sleep(16);
             else __builtin_amdgcn_s_sleep(64);
-            if (fences && wall_clock64() - last > 3000) {
+            if ((fences & 1) && wall_clock64() - last > 3000) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 last = wall_clock64();
@@ -299,7 +319,48 @@ __global__ void probe_sleeper_kernel(unsigned long long ticks, const unsigned lo
         }
         if (acc == 0x123456789ull) __builtin_trap();
     }
+    if (fences & 2) __syncthreads();
 }
+
+// the same sleeper holding ~130 vector registers per lane (64 doubles kept live across the sleep): what a resident
+// workgroup's REGISTER footprint does to a concurrent GEMM, apart from everything else about it (fences & 4 selects it)
+// park: 0 every wave sleeps in a loop; 1 wave 0 sleeps in a loop, the others wait for it at a workgroup barrier; 2 wave 0
+// sleeps in a loop, the others poll an LDS word it sets at the end (s_sleep between reads)
+}  // extern "C" (a template needs C++ linkage)
+template <int ND>
+__global__ __launch_bounds__(512) void probe_sleeper_fat_kernel(unsigned long long ticks, double* sink, int park) {
+    __shared__ volatile int done;
+    double v[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) v[i] = (double)(threadIdx.x + i);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) asm volatile("" : "+v"(v[i]));
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    if (park == 0 || threadIdx.x < 64) {
+        while (wall_clock64() - t0 < ticks) {
+            __builtin_amdgcn_s_sleep(64);
+#pragma unroll
+            for (int i = 0; i < ND; ++i) asm volatile("" : "+v"(v[i]));
+        }
+        if (threadIdx.x == 0) done = 1;
+    }
+    if (park == 1) __syncthreads();
+    if (park == 2 && threadIdx.x >= 64) {
+        while (!done) __builtin_amdgcn_s_sleep(64);
+    }
+    double t = 0.;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) t += v[i];
+    if (t == 123.456) sink[0] = t;
+}
+extern "C" {
+
+// streams of sleepers that may still be running: destroyed by a LATER call.  hipStreamDestroy WAITS for the stream's work on
+// this runtime -- until round 4 this probe destroyed the sleeper's stream right after the launch, i.e. it returned when the
+// sleeper was gone, and everything timed "beside" it ran alone (profiles/r03_resident_workgroup_cost.txt is void).
+static std::vector<hipStream_t> g_sleeper_streams;
 
 int gpmi_probe_resident(gpmi_ctx* c, int high_priority, int lds_bytes, int threads, double milliseconds, int poll_sleep,
                         int fences) {
@@ -307,6 +368,13 @@ int gpmi_probe_resident(gpmi_ctx* c, int high_priority, int lds_bytes, int threa
         !(milliseconds > 0.0) || milliseconds > 5000.0)
         return fail_arg("gpmi_probe_resident: bad argument");
     HIP_TRY(hipSetDevice(c->device));
+    // (poll_sleep < 0: keep the earlier sleepers -- several resident at once, each on a stream of its own)
+    if (poll_sleep >= 0) {
+        for (hipStream_t old : g_sleeper_streams) (void)hipStreamDestroy(old);   // waits for sleepers of earlier calls
+        g_sleeper_streams.clear();
+    } else {
+        poll_sleep = 0;
+    }
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     hipStream_t st = nullptr;
@@ -318,11 +386,29 @@ int gpmi_probe_resident(gpmi_ctx* c, int high_priority, int lds_bytes, int threa
             if (c->red.ensure(16 * 8) != hipSuccess) { (void)hipStreamDestroy(st); return fail_arg("gpmi_probe_resident: no scratch"); }
             flag = reinterpret_cast<const unsigned long long*>(c->red.as<double>() + 12);
         }
-        hipLaunchKernelGGL(probe_sleeper_kernel, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st,
-                           (unsigned long long)(milliseconds * 1e5), flag, poll_sleep, fences);      // wall_clock64: 100 MHz
-        e = hipGetLastError();
+        if (fences & 4) {
+            // fences bits 5..6: register footprint -- 0 ~130 per lane, 1 ~138, 2 ~146, 3 ~106
+            const int fat = (fences >> 5) & 3;
+            const void* fn = fat == 1 ? (const void*)probe_sleeper_fat_kernel<68> : fat == 2 ? (const void*)probe_sleeper_fat_kernel<72>
+                           : fat == 3 ? (const void*)probe_sleeper_fat_kernel<52> : (const void*)probe_sleeper_fat_kernel<64>;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+            if (e == hipSuccess && c->red.ensure(16 * 8) != hipSuccess) e = hipErrorOutOfMemory;
+            if (e == hipSuccess) {
+                const unsigned long long tk = (unsigned long long)(milliseconds * 1e5);
+                double* sink = c->red.as<double>();
+                const int park = (fences >> 3) & 3;
+                if (fat == 1) hipLaunchKernelGGL(probe_sleeper_fat_kernel<68>, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st, tk, sink, park);
+                else if (fat == 2) hipLaunchKernelGGL(probe_sleeper_fat_kernel<72>, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st, tk, sink, park);
+                else if (fat == 3) hipLaunchKernelGGL(probe_sleeper_fat_kernel<52>, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st, tk, sink, park);
+                else hipLaunchKernelGGL(probe_sleeper_fat_kernel<64>, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st, tk, sink, park);
+            }
+        } else {
+            hipLaunchKernelGGL(probe_sleeper_kernel, dim3(1), dim3((unsigned)threads), (size_t)lds_bytes, st,
+                               (unsigned long long)(milliseconds * 1e5), flag, poll_sleep, fences);      // wall_clock64: 100 MHz
+        }
+        if (e == hipSuccess) e = hipGetLastError();
     }
-    (void)hipStreamDestroy(st);          // released when the kernel has finished
+    g_sleeper_streams.push_back(st);     // NOT destroyed here: that would wait for the sleeper
     if (e != hipSuccess) return fail_runtime(e, "probe_sleeper launch");
     return GPMI_OK;
 }
@@ -391,6 +477,33 @@ int gpmi_probe_stream_overlap(gpmi_ctx* c, int n_high, int n_norm, double millis
     for (hipStream_t s : st) if (s) (void)hipStreamDestroy(s);
     if (e != hipSuccess) return fail_runtime(e, "gpmi_probe_stream_overlap");
     return GPMI_OK;
+}
+
+// The resident potrf128 server itself (panel_mfma.hip, experiment) beside a GEMM and nothing else: starts it on the context's
+// server stream with the given mode bits, times gpmi_probe_gemm's launches, stops it.  out as gpmi_probe_gemm.
+int gpmi_probe_gemm_beside_server(gpmi_ctx* c, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps, int mode,
+                                  double* out) {
+    if (!c || !out) return fail_arg("gpmi_probe_gemm_beside_server: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->pmail.p) {
+        HIP_TRY(c->pmail.ensure(sizeof(PotrfMail)));
+        HIP_TRY(hipMemset(c->pmail.p, 0, sizeof(PotrfMail)));
+        c->pserver.mail = c->pmail.as<PotrfMail>();
+    }
+    if (!c->sstream) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        HIP_TRY(hipStreamCreateWithPriority(&c->sstream, hipStreamNonBlocking, hi));
+    }
+    c->pserver.mode = mode;
+    if (mode) HIP_TRY(potrf_server_start(&c->pserver, c->sstream));
+    const int rc = gpmi_probe_gemm(c, M, N, K, lower, variant, reps, out);
+    if (mode) {
+        HIP_TRY(potrf_server_stop(&c->pserver, c->pstream));
+        HIP_TRY(hipStreamSynchronize(c->pstream));
+        HIP_TRY(hipStreamSynchronize(c->sstream));
+    }
+    return rc;
 }
 
 int gpmi_probe_hbm_write(gpmi_ctx* c, int64_t bytes, double* gbps) {

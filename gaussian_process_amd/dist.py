@@ -404,8 +404,12 @@ class DistGP:
         # take over the other XCDs' tails -- a rank's staircase of row blocks is dealt unevenly to the XCDs): on wherever no
         # kernel of another stream needs a whole CU meanwhile, i.e. not while this rank factors a diagonal block
         # -- measured on the 8-rank replay: the update itself runs 5-10 % faster, the panel solves that share the CUs with
-        # the resident workgroups 2-3x slower, the step not faster (profiles/r04_replay_ticket_ab.txt): off by default
-        self.ticket = int(os.environ.get("GPMI_DIST_TICKET", "0"))
+        # the resident workgroups 2-3x slower, the step not faster (profiles/r04_replay_ticket_ab.txt): off by default.  With
+        # real RCCL it may be the other way round: a per-tile launch loses 12 % for every shader engine in which another
+        # kernel holds a CU exclusively (LAB_NOTES.md), the ticket form only the CU's share; bench.py measures both forms
+        # before its timed region and takes the faster (self.ticket may be switched between steps)
+        _tk = os.environ.get("GPMI_DIST_TICKET", "0")
+        self.ticket = int(_tk) if _tk.lstrip("-").isdigit() else 0      # "auto" (bench.py decides by measurement) starts per-tile
         if os.environ.get("GPMI_DIST_BALANCE") == "0" and hasattr(self.ops, "set_option"):     # A/B switch of the XCD-balanced launch geometry
             self.ops.set_option("gemm_balance", 0)
         self.have_factor = False

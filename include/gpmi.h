@@ -215,6 +215,10 @@ int gpmi_device_info(gpmi_ctx* ctx, double* out, int count);
  * m rows (trsm128); *out_us = microseconds per launch; stamps_out (64 entries or NULL) = in-kernel clock stamps
  * of one instrumented launch (layout: csrc/panel_mfma.hip) */
 int gpmi_probe_panel(gpmi_ctx* ctx, int kind, int64_t m, int reps, double* out_us, uint64_t* stamps_out);
+/* diagnostic: gpmi_probe_gemm while the resident potrf128 server (option potrf_server, an experiment) sits on a CU with
+ * the given mode bits and is never used; 0: no server */
+int gpmi_probe_gemm_beside_server(gpmi_ctx* ctx, int64_t M, int64_t N, int64_t K, int lower, int variant, int reps, int mode,
+                                  double* out);
 /* diagnostic: n_high streams at the highest priority + n_norm at the default one, one sleeping one-wave kernel of
  * `milliseconds` on each; *wall_ms = time until all are done (about `milliseconds` when every stream has a hardware
  * queue of its own, a multiple when streams share one) */

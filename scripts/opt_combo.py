@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import gp_oracle as O
 from gaussian_process_amd import GPContext
-DEFAULTS = {"gemm_balance": 1, "gemm_ticket": 0, "gemm_reserve": 0, "gemm_persist": 1, "lookahead": 1, "shallow_min": 6144, "nb": 0}
+DEFAULTS = {"potrf_server": 0, "gemm_balance": 1, "gemm_ticket": 0, "gemm_reserve": 0, "gemm_persist": 1, "lookahead": 1, "shallow_min": 6144, "nb": 0}
 N, n = int(sys.argv[1]), int(sys.argv[2])
 X, y, Xs = O.synthetic_problem(N, 8, n)
 with GPContext(0) as ctx:

@@ -108,26 +108,46 @@ int main() {
         CHECK((SMrows <= DMA_MAX_SM) == (p.tri == 2), "SM=%ld tri=%d: the staircase must be used iff its table holds it", (long)SMrows, p.tri);
         tiles += check_plan(Tm, Tn, 0, 0, &map, true, 1, S); ++plans;
     }
-    // the XCD-balance model behind the choice of the supertile edge: against a brute-force count, and the choice itself
-    for (int Tn : {8, 16, 32, 40, 64, 72, 96, 104, 112, 120, 128, 200, 256}) {
+    // the deal of blocks to the 32 shader engines (block b -> XCD b % 8, engine (b >> 3) % 4, 8 CUs each) behind the choice
+    // of the supertile edge: the figure against an independent count, the chosen edge within 1 % of the best candidate,
+    // and the diagonal supertiles' live tiles spread evenly over the four engines of their XCD
+    for (int Tn : {8, 16, 32, 40, 64, 72, 96, 104, 112, 120, 128, 200, 256, 496}) {
+        double eff_of[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int S : {8, 4, 2, 1}) {
             TilePlan p;
             CHECK(plan_tiles(p, Tn + 1, Tn, 1, 0, false, nullptr, 0, 1, S), "plan");
-            long load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
+            long load[32], total = 0;
+            for (long& l : load) l = 0;
             for (int b = 0; b < p.nblocks; ++b) {
                 int ti, tj;
-                if (plan_block_to_tile(p, b, ti, tj) && plan_tile_live(p, ti, tj, nullptr)) { ++load[b & 7]; ++total; }
+                if (plan_block_to_tile(p, b, ti, tj) && plan_tile_live(p, ti, tj, nullptr)) { ++load[(b & 7) + 8 * ((b >> 3) & 3)]; ++total; }
             }
             long rounds = 0;
-            for (long l : load) rounds = std::max(rounds, (l + 31) / 32);
+            for (long l : load) rounds = std::max(rounds, (l + 7) / 8);
             const double eff = rounds ? (double)total / 256.0 / (double)rounds : 1.0;
-            CHECK(p.tri != 1 || fabs(eff - plan_tri_xcd_efficiency(Tn + 1, Tn, S)) < 1e-12, "efficiency model Tn=%d S=%d: %g vs %g", Tn, S, eff, plan_tri_xcd_efficiency(Tn + 1, Tn, S));
+            CHECK(fabs(eff - plan_xcd_efficiency(p, nullptr)) < 1e-12, "efficiency Tn=%d S=%d: %g vs %g", Tn, S, eff, plan_xcd_efficiency(p, nullptr));
+            eff_of[S] = eff;
+            if (p.tri == 1 && S >= 4 && Tn % S == 0) {
+                // one diagonal supertile: its S (S + 1) / 2 live tiles over the 4 engines differ by at most 1
+                const int s0 = 0;                                           // supertile 0 is (0, 0): blocks 8 q + 0
+                int per[4] = {0, 0, 0, 0};
+                for (int q = 0; q < S * S; ++q) {
+                    int ti, tj;
+                    const int b = ((s0 / 8) * S * S + q) * 8 + (s0 % 8);
+                    if (plan_block_to_tile(p, b, ti, tj) && plan_tile_live(p, ti, tj, nullptr)) ++per[q & 3];
+                }
+                const int mx = std::max(std::max(per[0], per[1]), std::max(per[2], per[3]));
+                const int mn = std::min(std::min(per[0], per[1]), std::min(per[2], per[3]));
+                CHECK(mx - mn <= 1 && per[0] + per[1] + per[2] + per[3] == S * (S + 1) / 2, "diagonal supertile S=%d: %d %d %d %d", S, per[0], per[1], per[2], per[3]);
+            }
         }
-        TilePlan p;
-        CHECK(plan_tiles(p, Tn + 1, Tn, 1, 0, false, nullptr, 0, 1), "plan");
-        double best = 0.0;
-        for (int S : {8, 4, 2}) if (S <= Tn) best = std::max(best, plan_tri_xcd_efficiency(Tn + 1, Tn, S));
-        CHECK(p.tri != 1 || p.S == 1 || plan_tri_xcd_efficiency(Tn + 1, Tn, p.S) >= best - 0.01 - 1e-12, "Tn=%d: chosen S=%d is not within 1 %% of the best deal", Tn, p.S);
+        if (Tn <= 256) {
+            TilePlan p;
+            CHECK(plan_tiles(p, Tn + 1, Tn, 1, 0, false, nullptr, 0, 1), "plan");
+            double best = 0.0;
+            for (int S : {8, 4, 2}) if (S <= Tn) best = std::max(best, eff_of[S]);
+            CHECK(p.tri != 1 || p.S == 1 || eff_of[p.S] >= best - 0.01 - 1e-12, "Tn=%d: chosen S=%d (%.4f) is not within 1 %% of the best deal (%.4f)", Tn, p.S, eff_of[p.S], best);
+        }
     }
     // refused arguments
     { TilePlan p; CHECK(!plan_tiles(p, 0, 4, 0, 0, false, nullptr, 0, 1), "Tm = 0 accepted");
