@@ -35,6 +35,7 @@ struct TilePlan {
     int nsuper = 0;
     int nblocks = 0;
     int sprefix[DMA_MAX_SM + 1];    // tri == 2: supertile row si holds its leftmost sprefix[si + 1] - sprefix[si] supertiles
+    const int32_t* row_ncols = nullptr;   // tri == 2: the row map (host copy here; the kernels' struct holds the device copy)
 };
 
 // block number -> tile; false: the block lies outside the tile grid (padding of the enumeration)
@@ -51,6 +52,30 @@ GPMI_HD bool plan_block_to_tile(const PT& p, int b, int& ti, int& tj) {
         si = 0;
         while (si + 1 < p.SM && p.sprefix[si + 1] <= s) ++si;
         sj = s - p.sprefix[si];
+        if (sj == p.sprefix[si + 1] - p.sprefix[si] - 1 && p.row_ncols) {
+            // the LAST live supertile of a staircase row is ragged (a row block's own diagonal block: its lower triangle):
+            // its live tiles first, row by row, the dead blocks behind them -- consecutive blocks go to the XCD's four
+            // shader engines in turn, and as a square the engine with the supertile's first columns carried most of it
+            int acc = 0;
+            for (int r = 0; r < p.S; ++r) {
+                const int tr = si * p.S + r;
+                int w = 0;
+                if (tr < p.Tm) {
+                    const int64_t nc = p.row_ncols[tr / p.row_block_tiles];
+                    int64_t wl = (nc + PLAN_TILE - 1) / PLAN_TILE - (int64_t)sj * p.S;
+                    if (wl > p.S) wl = p.S;
+                    if (wl > (int64_t)p.Tn - (int64_t)sj * p.S) wl = (int64_t)p.Tn - (int64_t)sj * p.S;
+                    w = wl > 0 ? (int)wl : 0;
+                }
+                if (q < acc + w) {
+                    ti = tr;
+                    tj = sj * p.S + (q - acc);
+                    return true;
+                }
+                acc += w;
+            }
+            return false;
+        }
     } else if (p.tri) {
         si = (int)((sqrtf(8.f * (float)s + 1.f) - 1.f) * 0.5f);
         while ((si + 1) * (si + 2) / 2 <= s) ++si;
@@ -140,6 +165,7 @@ inline bool plan_tiles(TilePlan& p, int64_t Tm, int64_t Tn, int lower, int64_t d
     p.lower = lower; p.diag_off = diag_off;
     p.row_block_tiles = row_block_tiles > 0 ? row_block_tiles : 1;
     p.tri = (lower && diag_off == 0 && 2 * p.Tn >= p.Tm) ? 1 : 0;
+    p.row_ncols = nullptr;
     const bool stairs = has_row_map && row_ncols_host && row_bands > 0 && !lower;
     // supertile edge: 8 tiles, but never wider than the launch -- a strip of Tn = 1 (a panel-internal update of 128
     // columns) enumerated in 8 x 8 supertiles is seven dead workgroups for every live one, and a dead workgroup still has
@@ -151,9 +177,9 @@ inline bool plan_tiles(TilePlan& p, int64_t Tm, int64_t Tn, int lower, int64_t d
     // (plan_tri_xcd_efficiency); never below 2 (an edge of 1 gives up all reuse of the operands in an XCD's L2)
     // a rank's staircase of row blocks (row map with a host copy) and mid-size triangular launches: the widest edge whose
     // deal is within 1 % of the best, by walking each candidate's blocks -- for launches small enough that a supertile more
-    // or less on one engine shows (up to 256 tile columns of a triangle, 16384 tiles of a staircase)
+    // or less on one engine shows (up to 256 tile columns of a triangle, 32768 tiles of a staircase)
     if (!force_S && balance_xcds && S > 2 &&
-        ((p.tri == 1 && !stairs && p.Tn <= 256) || (stairs && (int64_t)p.Tm * p.Tn <= 16384))) {
+        ((p.tri == 1 && !stairs && p.Tn <= 256) || (stairs && (int64_t)p.Tm * p.Tn <= 32768))) {
         double eff[4] = {0., 0., 0., 0.}, best = 0.0;
         int cand[4], nc = 0;
         for (int c = S; c >= 2 && nc < 4; c >>= 1) {
@@ -193,7 +219,7 @@ inline bool plan_tiles(TilePlan& p, int64_t Tm, int64_t Tn, int lower, int64_t d
         }
         if (ns >= 32 || S == 1 || force_S) {
             p.S = S; p.SM = SM; p.SN = SN; p.nsuper = ns;
-            if (use_stairs) p.tri = 2;
+            if (use_stairs) { p.tri = 2; p.row_ncols = row_ncols_host; }
             break;
         }
     }
