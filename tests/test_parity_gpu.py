@@ -1136,3 +1136,24 @@ def test_dev_sum_fixed_and_axpy2d_against_numpy():
     ops.axpy2d(Yd[30:40, 100:104], Xd[30:40, 100:104], -2.5)              # a general factor: one or two roundings (fma)
     want[30:40, 100:104] += -2.5 * X[30:40, 100:104]
     assert np.allclose(Yd.cpu().numpy(), want, rtol=4e-16, atol=1e-300)
+
+
+def test_resident_potrf_server_gives_the_same_bits(ctx, oracle):
+    """option potrf_server (round 4, an experiment kept for its measurements: LAB_NOTES.md): the 128 x 128 diagonal blocks are
+    factored by ONE resident workgroup fed through a mailbox instead of one launch each -- the same code on the same data in
+    the same order: LML, mean, variance and alpha bit for bit; the server leaves when the factorisation ends (a second fit
+    and a fit without it work afterwards)"""
+    N, n = 16384, 256
+    X, y, Xs = oracle.synthetic_problem(N, 8, n, seed=5)
+    out = []
+    for on in (0, 1, 1, 0):
+        ctx.set_option("potrf_server", on)
+        try:
+            lml = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+            mu, var = ctx.predict(Xs, want_sd=False)
+            out.append((lml, mu.copy(), var.copy(), ctx.alpha()))
+        finally:
+            ctx.set_option("potrf_server", 0)
+    for o in out[1:]:
+        assert o[0] == out[0][0]
+        assert np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2]) and np.array_equal(o[3], out[0][3])
