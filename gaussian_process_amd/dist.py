@@ -52,10 +52,14 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+LAYOUTS = ("cyclic", "snake", "balanced")
+
+
 def block_layout(T, G, layout):
     """Which rank owns row block b (b = 0 .. T; block T is the y block), for the two row-block distributions:
       "cyclic"  b -> b % G.
       "snake"   the same dealt boustrophedon: blocks 0 .. G-1 to ranks 0 .. G-1, blocks G .. 2G-1 to ranks G-1 .. 0, and so on.
+      "balanced" each group of G blocks dealt in the order that evens out the ranks' shares (below).
     Over the factorisation row block b is updated by b (b + 1) / 2 block products (step k < b touches its columns k + 1 .. b),
     so a rank's share of the work is the sum of that over its blocks, and cyclic dealing gives the last rank much more of it
     than the first: N = 65536, nb = 1024, 8 ranks -- rank 7 (blocks 7, 15, .. 63) carries 6384 units, rank 0 4592, the mean
@@ -63,12 +67,24 @@ def block_layout(T, G, layout):
     (+2.6 % over the mean instead of +16.9 %).  Either way at most one block per rank separates the ranks' row counts at
     any step, so the per-step balance of the panel solves is the cyclic one.
     Returns (owner[b] for b <= T, local index li[b], blocks[r] = that rank's blocks < T in increasing order)."""
-    if layout not in ("cyclic", "snake"):
-        raise ValueError("layout must be 'cyclic' or 'snake'")
-    own = []
-    for b in range(T + 1):
-        q, i = divmod(b, G)
-        own.append(G - 1 - i if (layout == "snake" and q % 2) else i)
+    if layout not in LAYOUTS:
+        raise ValueError("layout must be one of %s" % (LAYOUTS,))
+    if layout == "balanced":
+        # every group of G consecutive blocks is still dealt one block per rank (so the property above holds), but in the
+        # order that evens the shares out: groups from the heaviest (last) down, the group's heaviest block to the rank
+        # that carries least so far.  64 blocks, 8 ranks: worst share +0.4 % over the mean (snake +2.6 %)
+        own = [0] * (T + 1)
+        load = [0] * G
+        for g0 in range((T // G) * G, -1, -G):
+            grp = list(range(min(T, g0 + G - 1), g0 - 1, -1))            # heaviest first
+            for b, r in zip(grp, sorted(range(G), key=lambda r: (load[r], r))):
+                own[b] = r
+                load[r] += b * (b + 1) // 2 if b < T else 0
+    else:
+        own = []
+        for b in range(T + 1):
+            q, i = divmod(b, G)
+            own.append(G - 1 - i if (layout == "snake" and q % 2) else i)
     blocks = [[b for b in range(T) if own[b] == r] for r in range(G)]
     li = [0] * (T + 1)
     for r in range(G):
@@ -377,8 +393,8 @@ class DistGP:
         import os
         # how the row blocks are dealt to the ranks (block_layout): "snake" balances the ranks' shares of the update
         self.layout = layout if layout is not None else os.environ.get("GPMI_DIST_LAYOUT", "snake")
-        if self.layout not in ("cyclic", "snake"):
-            raise ValueError("layout must be 'cyclic' or 'snake'")
+        if self.layout not in LAYOUTS:
+            raise ValueError("layout must be one of %s" % (LAYOUTS,))
         # collectives: an object with TorchComm's five members; default by $GPMI_DIST_COMM: "torch" (RCCL through
         # torch.distributed's process group) or "rccl" (RCCL through this library's own C-ABI, RcclComm)
         if comm is None:

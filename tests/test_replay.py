@@ -47,7 +47,8 @@ def _replay_all_ranks(oracle, device, G, N, d, n, nb, la, layout="snake"):
 
 @pytest.mark.parametrize("G,N,d,n,nb,la,layout", [(2, 700, 3, 50, 128, 2, "snake"), (3, 520, 2, 33, 128, 2, "snake"),
                                                   (8, 1100, 4, 20, 128, 2, "snake"), (8, 700, 3, 50, 128, 1, "cyclic"),
-                                                  (4, 1100, 4, 20, 256, 0, "cyclic"), (4, 2300, 4, 20, 128, 2, "snake")])
+                                                  (4, 1100, 4, 20, 256, 0, "cyclic"), (4, 2300, 4, 20, 128, 2, "snake"),
+                                                  (8, 1100, 4, 20, 128, 2, "balanced"), (3, 1700, 2, 33, 128, 1, "balanced")])
 def test_replay_every_rank_cpu(oracle, G, N, d, n, nb, la, layout):
     _replay_all_ranks(oracle, "cpu", G, N, d, n, nb, la, layout)
 
@@ -57,15 +58,18 @@ def test_snake_layout_balances_the_update():
     share of the update at north_star's shape (64 blocks, 8 ranks) where cyclic dealing is 17 % over"""
     from gaussian_process_amd.dist import block_layout
     for T, G in ((64, 8), (32, 4), (6, 8), (9, 8), (5, 3), (1, 2), (128, 8)):
-        for layout in ("cyclic", "snake"):
+        for layout in ("cyclic", "snake", "balanced"):
             own, li, blocks = block_layout(T, G, layout)
             assert sorted(b for bl in blocks for b in bl) == list(range(T)) and len(own) == T + 1
             for r in range(G):
                 assert blocks[r] == sorted(blocks[r]) and all(own[b] == r and li[b] == j for j, b in enumerate(blocks[r]))
                 assert abs(len(blocks[r]) - T / G) < 1
+            for g0 in range(0, T + 1, G):          # one block per rank in every group of G: row counts differ by <= 1 block
+                grp = [own[b] for b in range(g0, min(T + 1, g0 + G))]
+                assert len(set(grp)) == len(grp)
             assert li[T] == len(blocks[own[T]])
     share = lambda bl: sum(b * (b + 1) // 2 for b in bl)
-    for layout, worst in (("cyclic", 1.169), ("snake", 1.026)):
+    for layout, worst in (("cyclic", 1.169), ("snake", 1.026), ("balanced", 1.004)):
         _, _, blocks = block_layout(64, 8, layout)
         w = [share(bl) for bl in blocks]
         assert abs(max(w) / (sum(w) / 8) - worst) < 2e-3, (layout, max(w) / (sum(w) / 8))
