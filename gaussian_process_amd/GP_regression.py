@@ -112,8 +112,8 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
     ctx = ctx or default_context()
     try:
         sg, ll = _select_kernel(ctx, kernel_choice, l, sigma)  # :125-136
-        lml = ctx.fit(X_train, y_train, sg, ll, noise_var)    # :126,138-140
-        mu_post, stand_devi = ctx.predict(X_test, want_sd=True)  # :127,143-148
+        # :126-127, 138-148 in one pass: K(X*, X) rides through the Cholesky below the y row (gpmi_fit_predict_resident)
+        lml, mu_post, stand_devi = ctx.fit_predict(X_train, y_train, X_test, sg, ll, noise_var, want_sd=True)
         n = mu_post.shape[0]
         L_ = ctx.post_chol(jitter)                            # :154
     finally:

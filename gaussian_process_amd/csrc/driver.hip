@@ -116,7 +116,7 @@ std::vector<int64_t> block_schedule(const gpmi_ctx* c, int64_t ncols) {
 //   (b)_k    ->  (a)_{k+1}             (panel stream waits on the event behind (b)_k)
 //   (b)_k    ->  (b)_{k+1}             (same stream)
 hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows,
-                            int64_t* info, bool account) {
+                            int64_t* info, bool account, int64_t carried_rows, const SweepFollower* follow) {
     hipError_t e;
     hipStream_t sm = c->stream;
     const std::vector<int64_t> widths = block_schedule(c, ncols);
@@ -127,7 +127,7 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     // panel kernels beside the trailing update use their small-LDS forms -- while there IS a trailing update of some length
     // to run beside: once the columns right of the panel are fewer than c->shallow_min, part (b) of a step is over long
     // before the panel chain is, and the one-launch forms (which then find empty CUs) are the shorter chain
-    GemmShallowScope shallow(la);
+    GemmShallowScope shallow(la || follow != nullptr);
     // (a) on the panel stream pays at mid sizes (N = 16384: -4 %, 32768: -1 %), where a launch's tail and the
     // panel chain are a visible share of a step; at the headline size it is worth 0.4 % and would put two
     // trailing-update launches in flight at once, which makes "time per launch" (the roofline figure) ambiguous
@@ -179,8 +179,9 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         c->span_end(sp, st);
         if (account && dma && counted) {
             c->stage_ms[GPMI_T_TRAIL_LAUNCHES] += 1.0;
-            // algorithmic: the lower triangle of the real rows plus the one row that carries y
-            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_algorithmic_flops(g, ncols - r0 + 1);
+            // algorithmic: the lower triangle of the real rows plus the one row that carries y (plus the test set's rows
+            // when they ride along: all of them reach every column, so only their number counts)
+            c->stage_ms[GPMI_T_TRAIL_FLOPS] += gemm_nt_algorithmic_flops(g, ncols - r0 + 1 + carried_rows);
         }
         return er;
     };
@@ -197,6 +198,24 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
         if (e != hipSuccess) return e;
         if (la && (e = c->order(sp_, sm)) != hipSuccess) return e;
         const int64_t r0 = k + nb;
+        if (follow) {
+            // block column k of L is final: the following rows' solve against L_kk and their update by it, behind their own
+            // step k-1 on their stream -- nothing of the factorisation waits for them
+            if ((e = c->order(sp_, follow->vs)) != hipSuccess) return e;
+            {
+                // as in solve_sweep: the small-LDS solve forms only for enough rows to matter beside the updates
+                GemmShallowScope solve_forms(follow->m >= 2048, true, true);
+                if ((e = trsm_block(follow->vs, A + k * ld + k, ld, follow->V + k, follow->ldv, follow->m, nb)) != hipSuccess) return e;
+            }
+            if (r0 < ncols) {
+                GemmArgs g;   // V[:, r0..) -= V[:, k..k+nb) * L[r0.., k..k+nb)^T
+                g.C = follow->V + r0; g.A = follow->V + k; g.B = A + r0 * ld + k;
+                g.ldc = g.lda = follow->ldv; g.ldb = ld;
+                g.M = follow->m; g.N = ncols - r0; g.K = nb;
+                g.mode = 0; g.lower = 0; g.diag_off = 0;
+                if ((e = launch_gemm_nt(follow->vs, g)) != hipSuccess) return e;
+            }
+        }
         k = r0;
         if (r0 >= ncols) continue;
         if (!la) {
@@ -231,33 +250,72 @@ void set_kernel_args(const gpmi_ctx* c, RbfArgs& r) {
     for (int i = 0; i < 11; ++i) r.kpv[i] = c->kpv[i];
 }
 
-int ensure_train_buffers(gpmi_ctx* c) {
+int ensure_train_buffers(gpmi_ctx* c, int64_t test_rows) {
     c->Np = round_up(c->N, TILE);
     c->ldA = c->Np + c->ld_pad;
-    c->Mp = c->Np + TILE;
+    c->Mp = c->Np + TILE + test_rows;
     HIP_TRY(c->A.ensure((size_t)c->Mp * c->ldA * sizeof(double)));
     HIP_TRY(c->info.ensure(sizeof(int64_t)));
     HIP_TRY(c->red.ensure(16 * sizeof(double)));
     return GPMI_OK;
 }
 
+// mean and variance (or standard deviation) from the row dots of v^T: h = [v_i . m for i < n_p | v_i . v_i for i < n_p]
+void meanvar_to_host(gpmi_ctx* c, const std::vector<double>& h, double* mu, double* out2, int want_sd) {
+    for (int64_t i = 0; i < c->n; ++i) {
+        if (mu) mu[i] = h[i];
+        if (out2) {
+            double kss = c->sig2;                          // diag(K_ss) == sigma^2 exactly for the RBF (GP_regression.py:147)
+            if (c->kind == 2) kss = 1.0;                   // periodic: exp(0)
+            else if (c->kind == 3) {                       // composite at sqdist 0, square K_ss: every factor is 1
+                const double* th = c->kpv;
+                kss = ((th[0] * th[0] + th[2] * th[2]) + th[5] * th[5]) + (th[8] * th[8] + th[10] * th[10]);
+            }
+            else if (c->kind == 1) {                       // linear: (x - c).(x - c)
+                kss = 0.0;
+                for (int64_t k = 0; k < c->d; ++k) {
+                    const double e = c->hXs[(size_t)i * c->d + k] - c->kp0;
+                    kss = kss + e * e;
+                }
+            }
+            const double var = kss - h[c->np_ + i];
+            out2[i] = want_sd ? std::sqrt(var) : var;      // sqrt(<0) -> NaN like np.sqrt (:148)
+        }
+    }
+}
+
 // K build + Cholesky (+ forward solve through the y row) + LML on the stream
 int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
-                   int64_t* bad_pivot) {
+                   int64_t* bad_pivot, bool with_test, double* mu, double* out2, int want_sd) {
     if (!c->have_train) return fail_arg("gpmi_factorize: no training set (call gpmi_set_train)");
     if (c->kind == 0 && (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma)))
         return fail_arg("gpmi_factorize: ell must be non-zero and hyper-parameters finite");
     if (std::isnan(noise_var)) return fail_arg("gpmi_factorize: noise_var is NaN");
     if (c->kind == 2 && c->d != 1) return fail_arg("gpmi_factorize: the periodic kernel is 1-D only (GP_regression.py:48)");
-    int rc = ensure_train_buffers(c);
+    // the test set's rows: inside the panel and update launches (1) or one block column behind on their own stream (2)
+    int form = 0;
+    if (with_test) {
+        // measured (profiles/r04_one_pass_ab.txt, ms for two calls / ride / follow): N = 2048 1.69 / 1.32 / 1.49, 8192 10.5 / 8.94 /
+        // 8.74, 16384 37.5 / 34.9 / 34.9, 32768 262.7 / 257.9 / 256.7, 65536 1702 / 1698 / 1710 -- the chip is work-conserving
+        // either way, and riding costs no launches: the default at every size
+        form = c->one_pass_form ? c->one_pass_form : 1;
+        if (form == 2 && !c->vstream) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            HIP_TRY(hipStreamCreateWithPriority(&c->vstream, hipStreamNonBlocking, lo));
+        }
+    }
+    int rc = ensure_train_buffers(c, with_test ? c->np_ : 0);
     if (rc) return rc;
     hipStream_t s = c->stream;
     c->have_factor = false;
+    c->v_in_A = false;
     c->have_vinv = false;
     c->have_vside = false;
     c->have_v = false;
     c->timers_reset({GPMI_T_KBUILD, GPMI_T_CHOL, GPMI_T_CHOL_PANEL, GPMI_T_CHOL_TRAIL, GPMI_T_LML,
                      GPMI_T_TRAIL_LAUNCHES, GPMI_T_TRAIL_FLOPS});
+    if (with_test) c->timers_reset({GPMI_T_KS, GPMI_T_SOLVE_V, GPMI_T_MEANVAR});
     c->sig2 = sigma * sigma;
     c->coef = -.5 * (1 / (ell * ell));      // GP_regression.py:19 evaluation order
     c->sigma = sigma; c->ell = ell;
@@ -278,15 +336,49 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     // the augmented rows: y then zeros (a4 rides in the factorisation)
     HIP_TRY(launch_fill_rows(s, A + c->Np * c->ldA, c->ldA, TILE, c->Np, 0.0));
     HIP_TRY(launch_set_yrow(s, A + c->Np * c->ldA, c->y.as<double>(), c->N, c->Np));
+    double* Vr = A + (c->Np + TILE) * c->ldA;
+    if (with_test) {                  // K(X*, X) below the y rows (a1 for K_s, GP_regression.py:127): they leave as v^T
+        sp = c->span_begin(GPMI_T_KS);
+        RbfArgs t;
+        t.A = c->Xs.as<double>(); t.B = c->X.as<double>();
+        t.nA = c->n; t.nB = c->N; t.d = c->d; t.row0 = 0; t.nrows = c->np_; t.ncols = c->Np;
+        set_kernel_args(c, t);
+        t.diag_add = 0.; t.symmetric = 0;
+        t.delta_square = (c->n == c->N) ? 1 : 0;
+        t.max_sq = box_max_sq(c->boxXs, c->boxX);
+        t.out = Vr; t.ld = c->ldA;
+        HIP_TRY(launch_rbf(s, t));
+        c->span_end(sp);
+    }
 
     sp = c->span_begin(GPMI_T_CHOL);
-    HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true));
+    if (form == 2) {
+        SweepFollower f;
+        f.V = Vr; f.ldv = c->ldA; f.m = c->np_; f.vs = c->vstream;
+        HIP_TRY(c->order(s, f.vs));                     // K(X*, X) is in place
+        size_t spv = c->span_begin(GPMI_T_SOLVE_V, f.vs);
+        HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Np + TILE, c->info.as<int64_t>(), true, 0, &f));
+        c->span_end(spv, f.vs);
+        HIP_TRY(c->order(f.vs, s));
+    } else {
+        HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true, with_test ? c->n : 0));
+    }
     c->span_end(sp);
 
     sp = c->span_begin(GPMI_T_LML);
     HIP_TRY(launch_lml_reduce(s, A, c->ldA, A + c->Np * c->ldA, c->N, c->red.as<double>()));
     c->span_end(sp);
 
+    std::vector<double> h;
+    if (with_test) {                  // a6 + a8 off the finished rows: mean_i = v_i . m, sum of squares for the variance
+        HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
+        sp = c->span_begin(GPMI_T_MEANVAR);
+        double* dot = c->vec.as<double>();
+        HIP_TRY(launch_row_dots(s, Vr, c->ldA, c->np_, c->Np, A + c->Np * c->ldA, dot, dot + c->np_));
+        c->span_end(sp);
+        h.resize(2 * (size_t)c->np_);
+        HIP_TRY(hipMemcpyAsync(h.data(), dot, h.size() * 8, hipMemcpyDeviceToHost, s));
+    }
     double red[2];
     int64_t info;
     HIP_TRY(hipMemcpyAsync(red, c->red.p, sizeof red, hipMemcpyDeviceToHost, s));
@@ -314,6 +406,12 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     if (lml) *lml = -.5 * red[1] - red[0] - (double)c->N / 2.0 * std::log(2 * M_PI);
     c->have_factor = true;
     c->factor_fused = tuning().panel_fused;
+    if (with_test) {
+        c->v_in_A = true;
+        c->ldV = c->ldA;
+        c->have_v = true;
+        meanvar_to_host(c, h, mu, out2, want_sd);
+    }
     return GPMI_OK;
 }
 

@@ -78,6 +78,7 @@ int gpmi_ctx_destroy(gpmi_ctx* c) {
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->pstream);
     if (c->sstream) (void)hipStreamDestroy(c->sstream);
+    if (c->vstream) (void)hipStreamDestroy(c->vstream);
     delete c;
     return GPMI_OK;
 }
@@ -138,6 +139,9 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
     } else if (!strcmp(name, "shallow_min")) {
         if (value < 0) return fail_arg("shallow_min must be >= 0");
         c->shallow_min = value;
+    } else if (!strcmp(name, "one_pass_form")) {
+        if (value < 0 || value > 2) return fail_arg("one_pass_form must be 0 (by size), 1 (rows ride) or 2 (rows follow)");
+        c->one_pass_form = (int)value;
     } else if (!strcmp(name, "lanes")) {
         if (value < 0 || value > 8) return fail_arg("lanes must be 0 (by size) .. 8");
         c->lanes = (int)value;
@@ -425,6 +429,7 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     hipStream_t s = c->stream;
     c->timers_reset({GPMI_T_KS, GPMI_T_SOLVE_V, GPMI_T_MEANVAR});
     c->have_v = false;
+    c->v_in_A = false;
     c->ldV = c->Np + c->ld_pad;
     HIP_TRY(c->V.ensure((size_t)c->np_ * c->ldV * 8));
     HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
@@ -457,27 +462,22 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     HIP_TRY(hipStreamSynchronize(s));
     c->timers_collect();
     c->have_v = true;
-    for (int64_t i = 0; i < c->n; ++i) {
-        if (mu) mu[i] = h[i];
-        if (out2) {
-            double kss = c->sig2;                          // diag(K_ss) == sigma^2 exactly for the RBF (GP_regression.py:147)
-            if (c->kind == 2) kss = 1.0;                   // periodic: exp(0)
-            else if (c->kind == 3) {                       // composite at sqdist 0, square K_ss: every factor is 1
-                const double* th = c->kpv;
-                kss = ((th[0] * th[0] + th[2] * th[2]) + th[5] * th[5]) + (th[8] * th[8] + th[10] * th[10]);
-            }
-            else if (c->kind == 1) {                       // linear: (x - c).(x - c)
-                kss = 0.0;
-                for (int64_t k = 0; k < c->d; ++k) {
-                    const double e = c->hXs[(size_t)i * c->d + k] - c->kp0;
-                    kss = kss + e * e;
-                }
-            }
-            const double var = kss - h[c->np_ + i];
-            out2[i] = want_sd ? std::sqrt(var) : var;      // sqrt(<0) -> NaN like np.sqrt (:148)
-        }
-    }
+    meanvar_to_host(c, h, mu, out2, want_sd);
     return GPMI_OK;
+}
+
+// prediction() in one pass (a11 = a1 .. a8 for a training AND a test set known up front, GP_regression.py:109-156): the
+// rows K(X*, X) are appended below the y row, so the panel solves and trailing updates of the Cholesky turn them into
+// v^T = K_s^T L^-T on the way (a7 costs no launches of its own and fills the chip while the last, short updates leave
+// it idle), and mean / variance are read off behind the LML.  Same results as gpmi_factorize + gpmi_predict_resident to
+// rounding (the block widths of the two sweeps can differ).
+int gpmi_fit_predict_resident(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot,
+                              double* mu, double* out2, int want_sd) {
+    if (!c) return fail_arg("gpmi_fit_predict: null context");
+    if (!c->have_test) return fail_arg("gpmi_fit_predict: no test set (call gpmi_set_test)");
+    HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
+    return factorize_impl(c, sigma, ell, noise_var, lml, bad_pivot, true, mu, out2, want_sd);
 }
 
 int gpmi_predict(gpmi_ctx* c, const double* Xs, int64_t n, double* mu, double* out2, int want_sd) {
@@ -639,7 +639,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     r.out = P; r.ld = c->ldP;
     HIP_TRY(launch_rbf(s, r));
     GemmArgs g;  // P -= v^T v  (rows of V are the columns of v)
-    g.C = P; g.A = g.B = c->V.as<double>();
+    g.C = P; g.A = g.B = c->v_rows();
     g.ldc = c->ldP; g.lda = g.ldb = c->ldV;
     g.M = g.N = np_; g.K = c->Np; g.mode = 0; g.lower = 1; g.diag_off = 0;
     HIP_TRY(launch_gemm_nt(s, g));

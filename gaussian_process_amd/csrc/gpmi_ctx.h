@@ -93,6 +93,7 @@ struct gpmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;    // main stream: K build, trailing updates, reductions
     hipStream_t pstream = nullptr;   // high-priority stream: panel factorisations (lookahead)
+    hipStream_t vstream = nullptr;   // one-pass prediction, form "follow": the test set's sweep, one block column behind the Cholesky
     hipStream_t sstream = nullptr;   // experiment (option potrf_server): the stream the resident potrf128 workgroup lives on
     gpmi::PotrfServerState pserver;  // its mailbox and sequence numbers
     DevBuf pmail;
@@ -103,6 +104,8 @@ struct gpmi_ctx {
     int timing = 1;
     int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
     int64_t shallow_min = 6144; // under lookahead, panels with fewer columns left than this use the one-launch panel kernels (0: never)
+    int one_pass_form = 0;  // gpmi_fit_predict_resident: 1 the test set's rows ride in the panel and update launches, 2 they follow on a
+                            // stream of their own (panel k done -> their solve against L_kk -> their update), 0 = by size
     int lanes = 0;          // gpmi_lml_batch: factorisations in flight (0 = by size)
     std::vector<gpmi_ctx*> lane_ctx;   // the extra lanes (own streams and workspaces), created on demand
     int ramp = 0;           // block-width schedule, bit mask: 1 ramp up at the start, 2 half width over the last blocks (count in bits 4.., default 3),
@@ -126,6 +129,8 @@ struct gpmi_ctx {
     // test set
     int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
     bool have_test = false, have_v = false;
+    bool v_in_A = false;     // v^T is resident in the rows of A below the y rows (gpmi_fit_predict_resident), not in V
+    double* v_rows() { return v_in_A ? A.as<double>() + (Np + 128) * ldA : V.as<double>(); }
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;
@@ -195,11 +200,21 @@ namespace gpmi {
 hipError_t panel_factor(hipStream_t s, double* A, int64_t ld, int64_t nb, int64_t mrows, int64_t col_offset,
                         int64_t* info);
 hipError_t trsm_block(hipStream_t s, const double* L, int64_t ldl, double* X, int64_t ldx, int64_t m, int64_t nb);
+// rows that follow the factorisation on a stream of their own: V (m x ncols, leading dimension ldv) <- V L^-T
+struct SweepFollower {
+    double* V = nullptr;
+    int64_t ldv = 0, m = 0;
+    hipStream_t vs = nullptr;
+};
 hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, int64_t nrows, int64_t* info,
-                            bool account);
+                            bool account, int64_t carried_rows = 0, const SweepFollower* follow = nullptr);
 hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri = false);
 void set_kernel_args(const gpmi_ctx* c, RbfArgs& r);
-int ensure_train_buffers(gpmi_ctx* c);
-int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot);
+int ensure_train_buffers(gpmi_ctx* c, int64_t test_rows = 0);
+// with_test: the test set's rows K(X*, X) ride below the y rows (they come out as v^T = K_s^T L^-T, a7 inside a3) and
+// mean / variance (a6, a8) are read off them behind the LML
+int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot,
+                   bool with_test = false, double* mu = nullptr, double* out2 = nullptr, int want_sd = 1);
+void meanvar_to_host(gpmi_ctx* c, const std::vector<double>& h, double* mu, double* out2, int want_sd);
 
 }  // namespace gpmi

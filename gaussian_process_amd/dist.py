@@ -6,8 +6,8 @@ Reference path: GP_regression.py:126-148 / tune_hyperparms_regression.py:306-312
 reference itself is single-process NumPy; SURVEY.md section 8e is the design this follows).
 
 Layout.  NB-row blocks of K + sI; global block b lives on rank owner[b] (block_layout: the blocks
-dealt boustrophedon by default -- "snake" -- which balances the ranks' shares of the update; plain
-b % G with layout="cyclic"), stacked in increasing b in that rank's local matrix A (rows) x (Np + pad)
+dealt one per rank in every group of G, in the order that evens out the ranks' shares of the update -- "balanced", the
+default; boustrophedon with layout="snake", plain b % G with layout="cyclic"), stacked in increasing b in that rank's local matrix A (rows) x (Np + pad)
 -- row-major, so the rank holds whole rows of L.  One extra 128-row block carries y (owner[T]): the
 factorisation sweeps it like any other row block, so it ends as m = L^-1 y.
 
@@ -391,8 +391,8 @@ class DistGP:
         if nb <= 0 or nb % 128:
             raise ValueError("nb must be a positive multiple of 128")
         import os
-        # how the row blocks are dealt to the ranks (block_layout): "snake" balances the ranks' shares of the update
-        self.layout = layout if layout is not None else os.environ.get("GPMI_DIST_LAYOUT", "snake")
+        # how the row blocks are dealt to the ranks (block_layout): "balanced" evens out the ranks' shares of the update
+        self.layout = layout if layout is not None else os.environ.get("GPMI_DIST_LAYOUT", "balanced")
         if self.layout not in LAYOUTS:
             raise ValueError("layout must be one of %s" % (LAYOUTS,))
         # collectives: an object with TorchComm's five members; default by $GPMI_DIST_COMM: "torch" (RCCL through

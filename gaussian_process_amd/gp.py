@@ -205,6 +205,23 @@ class GPContext:
         self.set_test(Xs)
         return self.predict_resident(want_sd)
 
+    def fit_predict_resident(self, sigma, l, noise_var, want_sd=True):
+        """prediction() in one pass (GP_regression.py:109-156) for the resident training and test sets: the rows
+        K(X*, X) ride through the Cholesky below the y row.  Returns (lml, mu, sd_or_var)."""
+        lml = C.c_double()
+        bad = C.c_int64()
+        mu = np.empty(self.n)
+        o2 = np.empty(self.n)
+        st = self._lib.gpmi_fit_predict_resident(self._h, scalar(sigma, "sigma"), scalar(l, "l"), scalar(noise_var, "noise_var"),
+                                                 C.byref(lml), C.byref(bad), ptr(mu), ptr(o2), 1 if want_sd else 0)
+        check(st, bad.value)
+        return lml.value, mu, o2
+
+    def fit_predict(self, X, y, Xs, sigma, l, noise_var, want_sd=True):
+        self.set_train(X, y)
+        self.set_test(Xs)
+        return self.fit_predict_resident(sigma, l, noise_var, want_sd)
+
     def post_chol(self, jitter):
         out = np.empty((self.n, self.n))
         bad = C.c_int64()

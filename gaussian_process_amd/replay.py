@@ -72,7 +72,7 @@ class ReplaySource:
 
 
 class ReplayComm:
-    def __init__(self, rank, size, source: ReplaySource, layout="snake"):
+    def __init__(self, rank, size, source: ReplaySource, layout="balanced"):
         if not (0 <= rank < size):
             raise ValueError("rank must be in [0, size)")
         self.rank, self.size, self.src = int(rank), int(size), source
@@ -235,7 +235,7 @@ class ReplayComm:
                            % (self.rank, self.size), "ranks": self.size, "env": {}}
 
 
-def replay_rank(device_index, source: ReplaySource, rank, size, X, y, Xs, lookahead=2, ops=None, layout="snake"):
+def replay_rank(device_index, source: ReplaySource, rank, size, X, y, Xs, lookahead=2, ops=None, layout="balanced"):
     """DistGP of rank `rank` in a world of `size`, its collectives served from `source`; train / test sets resident"""
     gp = DistGP(device_index, nb=source.NB, comm=ReplayComm(rank, size, source, layout), lookahead=lookahead, ops=ops,
                 layout=layout)

@@ -150,6 +150,14 @@ int gpmi_predict_resident(gpmi_ctx* ctx, double* mu, double* out2, int want_sd);
 int gpmi_predict(gpmi_ctx* ctx, const double* Xs, int64_t n, double* mu, double* out2,
                  int want_sd);
 
+/* prediction() in one pass: gpmi_factorize + gpmi_predict_resident for a training and a test set that are both
+ * resident (gpmi_set_train, gpmi_set_test), GP_regression.py:109-156 (a1-a8).  K(X*, X) rides below the y row through
+ * the Cholesky, so a7 (v = L^-1 K_s) has no launches of its own.  lml / bad_pivot as gpmi_factorize, mu / out2 / want_sd
+ * as gpmi_predict_resident; alpha, post_chol and lml_grad work on the result as after the two calls.  Results agree with
+ * the two-call form to rounding (not bit for bit: the two sweeps' block widths differ). */
+int gpmi_fit_predict_resident(gpmi_ctx* ctx, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot,
+                              double* mu, double* out2, int want_sd);
+
 /* L_ = cholesky(K_ss + jitter*I - v.T @ v)            GP_regression.py:154
  * for the test set of the last predict; L_out: n x n row-major, zeros above the
  * diagonal.   */

@@ -1160,3 +1160,86 @@ def test_resident_potrf_server_gives_the_same_bits(ctx, oracle):
     for o in out[1:]:
         assert o[0] == out[0][0]
         assert np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2]) and np.array_equal(o[3], out[0][3])
+
+
+# ---- prediction() in one pass: the test set's rows ride through the Cholesky (gpmi_fit_predict_resident) --------------
+@pytest.mark.parametrize("name", golden_names())
+def test_fit_predict_one_pass_vs_reference_golden(ctx, name):
+    """the one-pass form against the reference's own outputs, same tolerances as the two-call form; alpha, m, the
+    diagonal and the posterior-sample factor (f1) read off the same resident state afterwards"""
+    g = golden(name)
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    lml, mu, sd = ctx.fit_predict(X, y, Xs, float(g["sigma"]), float(g["ell"]), float(g["s"]), want_sd=True)
+    assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
+    assert np.allclose(mu, g["mu"], rtol=0, atol=MU_ATOL)
+    assert np.allclose(sd, g["sd"], rtol=0, atol=SD_ATOL)
+    assert relmax(ctx.diag(), g["diagL"]) <= DIAG_RTOL
+    assert relmax(ctx.m(), g["m"]) <= M_RTOL
+    assert relmax(ctx.alpha(), g["alpha"]) <= ALPHA_RTOL
+    L_ = ctx.post_chol(1e-6)
+    fpost = mu.reshape(-1, 1) + L_ @ g["normals"]
+    assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
+
+
+@pytest.mark.parametrize("N,d,n", [(1, 1, 1), (130, 2, 1), (300, 1, 37), (2048, 8, 200), (5000, 3, 129), (12500, 8, 700),
+                                   (16384, 8, 1024)])
+def test_fit_predict_one_pass_matches_two_calls(ctx, oracle, N, d, n):
+    """same factor (the carried rows do not enter L: LML, m, diagonal and alpha bit for bit), mean and variance to rounding
+    (the block widths of the carried rows' sweep are the factorisation's), on both sides of the lookahead threshold; the
+    two-call form still works afterwards on the same context (the matrix buffer shrinks back)"""
+    X, y, Xs = oracle.synthetic_problem(N, d, n, seed=11)
+    lml2 = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    mu2, var2 = ctx.predict(Xs, want_sd=False)
+    a2, m2, d2 = ctx.alpha(), ctx.m(), ctx.diag()
+    P2 = ctx.post_chol(1e-6) if n <= 1024 else None
+    scale = max(1.0, np.abs(a2).max() * 1e-3)
+    for form in (1, 2, 0):          # the rows ride inside the launches / follow on their own stream / chosen by size
+        ctx.set_option("one_pass_form", form)
+        try:
+            lml1, mu1, var1 = ctx.fit_predict(X, y, Xs, 1.0, 2.0, 5e-4, want_sd=False)
+            assert lml1 == lml2
+            assert np.array_equal(ctx.m(), m2) and np.array_equal(ctx.diag(), d2) and np.array_equal(ctx.alpha(), a2)
+            assert np.max(np.abs(mu1 - mu2)) <= 1e-11 * scale, (form, np.max(np.abs(mu1 - mu2)))
+            assert np.max(np.abs(var1 - var2)) <= 1e-12, (form, np.max(np.abs(var1 - var2)))
+            if P2 is not None:
+                P1 = ctx.post_chol(1e-6)
+                assert np.max(np.abs(P1 - P2)) <= 1e-7 * max(1.0, np.abs(P2).max())     # the factor of a matrix of ~1e-6 pivots
+            lml1b, mu1b, var1b = ctx.fit_predict_resident(1.0, 2.0, 5e-4, want_sd=False)
+            assert lml1b == lml1 and np.array_equal(mu1b, mu1) and np.array_equal(var1b, var1)      # deterministic
+        finally:
+            ctx.set_option("one_pass_form", 0)
+    lml3 = ctx.factorize(1.0, 2.0, 5e-4)
+    mu3, var3 = ctx.predict_resident(want_sd=False)
+    assert lml3 == lml2 and np.array_equal(mu3, mu2) and np.array_equal(var3, var2)
+
+
+def test_fit_predict_one_pass_cfg2_vs_oracle(ctx, oracle):
+    """BASELINE config 2 through the one-pass form: mean / variance against the oracle at north_star's 1e-8"""
+    X, y, Xs = oracle.synthetic_problem(16384, 8, 1024)
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 2.0, 5e-4)
+    lml, mu, var = ctx.fit_predict(X, y, Xs, 1.0, 2.0, 5e-4, want_sd=False)
+    assert np.max(np.abs(mu - ref["mu"])) <= 1e-8
+    assert np.max(np.abs(var - ref["var"])) <= 1e-8
+    assert abs(lml - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
+
+
+def test_fit_predict_one_pass_errors(ctx, oracle):
+    """no test set -> ValueError; a matrix that is not positive definite -> LinAlgError with the two-call form's pivot;
+    kernels other than the squared exponential ride the same way"""
+    from gaussian_process_amd import GPContext
+    X, y, Xs = oracle.synthetic_problem(400, 2, 30, seed=3)
+    with GPContext(0) as c2:
+        c2.set_train(X, y)
+        with pytest.raises(ValueError):
+            c2.fit_predict_resident(1.0, 2.0, 5e-4)
+        c2.set_test(Xs)
+        with pytest.raises(np.linalg.LinAlgError) as e2:
+            c2.factorize(1.0, 2.0, -2.0)
+        with pytest.raises(np.linalg.LinAlgError) as e1:
+            c2.fit_predict_resident(1.0, 2.0, -2.0)
+        assert str(e1.value) == str(e2.value)
+        c2.set_kernel("lin", 0.5)
+        lml2 = c2.factorize(1.0, 2.0, 5e-2)
+        mu2, sd2 = c2.predict_resident()
+        lml1, mu1, sd1 = c2.fit_predict_resident(1.0, 2.0, 5e-2)
+        assert lml1 == lml2 and np.allclose(mu1, mu2, rtol=0, atol=1e-10) and np.allclose(sd1, sd2, rtol=0, atol=1e-10, equal_nan=True)
