@@ -409,6 +409,7 @@ def run_replay(args):
     nb = int(os.environ.get("GPMI_DIST_NB", str(nb_auto)))
     lookahead = int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2"))
     layout = os.environ.get("GPMI_DIST_LAYOUT", "balanced")
+    one_pass = os.environ.get("GPMI_BENCH_TWO_CALLS") != "1"      # the bench line's call form (prediction() in one pass)
     # T(1 GPU): the product's single-GPU path, same step as the bench line
     wd.beat("single-GPU reference")
     t1_ms = None
@@ -420,9 +421,13 @@ def run_replay(args):
                 if k == args.warmup:
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                lml1 = ctx.factorize(sigma, ell, s)
-                ctx.alpha()
-                ctx.predict_resident(want_sd=False)
+                if one_pass:
+                    lml1, _, _ = ctx.fit_predict_resident(sigma, ell, s, want_sd=False)
+                    ctx.alpha()
+                else:
+                    lml1 = ctx.factorize(sigma, ell, s)
+                    ctx.alpha()
+                    ctx.predict_resident(want_sd=False)
             torch.cuda.synchronize()
             t1_ms = (time.perf_counter() - t0) / args.steps * 1e3
     wd.beat("source factorisation (block rows %d)" % nb)
@@ -433,6 +438,10 @@ def run_replay(args):
         gp = replay_rank(0, src, r, G, X, y, Xs, lookahead=lookahead, layout=layout)
 
         def step():
+            if one_pass:
+                lml, mu, var = gp.fit_predict_resident(sigma, ell, s, want_sd=False)
+                alpha = gp.alpha()
+                return lml, mu, var, alpha
             lml = gp.factorize(sigma, ell, s)
             alpha = gp.alpha()
             mu, var = gp.predict_resident(want_sd=False)
@@ -475,6 +484,7 @@ def run_replay(args):
             "streams, events, pack copies and Python issue are a real rank's; collectives are device copies out of a stored "
             "factorisation (gaussian_process_amd/replay.py), so xGMI time is NOT in these numbers",
             "of": G, "ranks": res, "block_rows": nb, "lookahead": lookahead, "layout": layout,
+            "call_form": "one pass (fit_predict_resident + alpha)" if one_pass else "two calls (factorize + alpha + predict_resident)",
             "config": {"workload": "GP fit+predict N=%d d=%d n_test=%d" % (N, d, n), "N": N, "d": d, "n_test": n},
             "t1_ms": t1_ms, "t1_what": "single-GPU path (GPContext), same step, this run",
             "worst_rank_ms": worst,
@@ -588,7 +598,15 @@ def main():
 
         wd.beat("train / test sets resident")
 
+        dist_one_pass = os.environ.get("GPMI_BENCH_TWO_CALLS") != "1"
+
         def step(k=-1):
+            if dist_one_pass:       # prediction() in one pass: every rank's share of the test rows rides below its blocks
+                wd.beat("step %d fit + predict" % k)
+                lml, mu, var = gp.fit_predict_resident(sigma, ell, s, want_sd=False)
+                wd.beat("step %d alpha" % k)
+                alpha = gp.alpha()
+                return lml, mu, var, alpha
             wd.beat("step %d fit" % k)
             lml = gp.factorize(sigma, ell, s)
             wd.beat("step %d alpha" % k)
@@ -756,6 +774,9 @@ def main():
             out["backend"] = backend
             out["config"]["block_rows"] = nb_used
             out["config"]["row_block_layout"] = gp.layout
+            out["config"]["call_form"] = ("one pass: DistGP.fit_predict_resident (each rank's share of the test rows rides below "
+                                          "its row blocks; no message of their own) + alpha" if dist_one_pass
+                                          else "two calls: factorize + alpha + predict_resident")
             out["config"]["update_form"] = update_form if update_form is not None else ("ticket" if gp.ticket else "per-tile")
             out["stages_ms"] = stage            # last step, rank 0: fit / alpha / predict wall
             out["per_rank_ms"] = per_rank

@@ -552,7 +552,11 @@ class DistGP:
         self.nloc = len(self.my_blocks)
         self.ry = self._own[self.T]                  # rank that carries the y block
         self.yrow = self.nloc * NB if self.rank == self.ry else None
-        self.rows = self.nloc * NB + (YB if self.rank == self.ry else 0)
+        # rows_base: my blocks (+ the y rows); `rows` = rows_base + the test rows that ride along in the one-pass form
+        # (fit_predict_resident), 0 of them otherwise -- _set_tail
+        self.rows_base = self.nloc * NB + (YB if self.rank == self.ry else 0)
+        self.rows = self.rows_base
+        self._tail_cache = {}
         self.ld = self.Np + self.ld_pad
         # X, y replicated (N*(d+1)*8 bytes); broadcast from rank 0 so every rank factors the same data
         self.X = torch.from_numpy(X).to(self.dev)
@@ -586,6 +590,16 @@ class DistGP:
         self.info = torch.full((1,), INT64_MAX, dtype=torch.int64, device=self.dev)
         self.red = self._tensor(max(self.nloc, 1) + 1, 2)
         self.m = self._tensor(self.Np)
+        self._set_tail(0)
+        self.have_factor = False
+        self.have_test = False
+
+    def _build_rowmaps(self, vrows):
+        """the row maps of my update launches when `vrows` full-width rows (test rows riding along) follow my blocks
+        (and the y rows): per step, per 128-row band, the number of columns the band updates"""
+        NB = self.NB
+        tail_bands = (YB // 128 if self.rank == self.ry else 0) + vrows // 128
+        tb = {}
         # per step: number of columns each 128-row band of my rows below block k updates (the part of the
         # trailing matrix on or below the diagonal, to the 128-column tile)
         bands = NB // 128
@@ -596,14 +610,13 @@ class DistGP:
             t = []
             for li in range(ls, self.nloc):        # a block reaches its own diagonal: lower triangle only, per 128-row band
                 t += [(self.my_blocks[li] - k - 1) * NB + (q + 1) * 128 for q in range(bands)]
-            if self.rank == self.ry:
-                t += [self.Np - (k + 1) * NB] * (YB // 128)
+            t += [self.Np - (k + 1) * NB] * tail_bands
             tabs.append(t)
         flat = [v for t in tabs for v in t] or [0]
-        self.rowmap = torch.tensor(flat, dtype=torch.int32, device=self.dev)
-        self.rowmap_h = np.ascontiguousarray(flat, dtype=np.int32)
-        self.rowmap_off = offs
-        self.rowmap_len = [len(t) for t in tabs]
+        tb["rowmap"] = torch.tensor(flat, dtype=torch.int32, device=self.dev)
+        tb["rowmap_h"] = np.ascontiguousarray(flat, dtype=np.int32)
+        tb["rowmap_off"] = offs
+        tb["rowmap_len"] = [len(t) for t in tabs]
         # lookahead part (b) of step k: my rows of blocks > k+1 update columns from block k+2 on
         tabs, offs = [], []
         for k in range(self.T - 2):
@@ -612,14 +625,13 @@ class DistGP:
             t = []
             for li in range(ls, self.nloc):
                 t += [(self.my_blocks[li] - k - 2) * NB + (q + 1) * 128 for q in range(bands)]
-            if self.rank == self.ry:
-                t += [self.Np - (k + 2) * NB] * (YB // 128)
+            t += [self.Np - (k + 2) * NB] * tail_bands
             tabs.append(t)
         flat = [v for t in tabs for v in t] or [0]
-        self.rowmapB = torch.tensor(flat, dtype=torch.int32, device=self.dev)
-        self.rowmapB_h = np.ascontiguousarray(flat, dtype=np.int32)
-        self.rowmapB_off = offs
-        self.rowmapB_len = [len(t) for t in tabs]
+        tb["rowmapB"] = torch.tensor(flat, dtype=torch.int32, device=self.dev)
+        tb["rowmapB_h"] = np.ascontiguousarray(flat, dtype=np.int32)
+        tb["rowmapB_off"] = offs
+        tb["rowmapB_len"] = [len(t) for t in tabs]
         # critical-path-first schedule: the diagonal block of block row k+2 is updated ahead of part (b)
         # (it is the next but one to be factored), so its bands update nothing in (b)
         flatC = []
@@ -629,10 +641,24 @@ class DistGP:
             if ls1 < self.nloc and self.my_blocks[ls1] == k + 2:
                 t[:bands] = [0] * bands
             flatC += t
-        self.rowmapC = torch.tensor(flatC or [0], dtype=torch.int32, device=self.dev)
-        self.rowmapC_h = np.ascontiguousarray(flatC or [0], dtype=np.int32)
-        self.have_factor = False
-        self.have_test = False
+        tb["rowmapC"] = torch.tensor(flatC or [0], dtype=torch.int32, device=self.dev)
+        tb["rowmapC_h"] = np.ascontiguousarray(flatC or [0], dtype=np.int32)
+        return tb
+
+    def _set_tail(self, vrows):
+        """make `vrows` (a multiple of 128) the number of test rows that ride below my blocks: row count, row maps, room in A"""
+        if vrows % 128:
+            raise ValueError("tail rows must be a multiple of 128")
+        tb = self._tail_cache.get(vrows)
+        if tb is None:
+            tb = self._tail_cache[vrows] = self._build_rowmaps(vrows)
+        for key, v in tb.items():
+            setattr(self, key, v)
+        self.rows = self.rows_base + vrows
+        if self.A.shape[0] < max(self.rows, 1):
+            self.A = None                                 # free first: a rank's matrix can be most of the memory
+            self.A = self._tensor(max(self.rows, 1), self.ld)
+            self.have_factor = False
 
     def _ticket(self, on):
         """context manager: the enclosed update launches use the ticket form of the GEMM (HIP primitives only)"""
@@ -906,7 +932,7 @@ class DistGP:
         self._wait("main", ev_bcast)
         self._wait("main", self._record("crit"))
 
-    def factorize(self, sigma, ell, noise_var):
+    def factorize(self, sigma, ell, noise_var, _ride=False):
         """K + sI -> L (distributed), m = L^-1 y; returns the log-marginal-likelihood
         (tune_hyperparms_regression.py:312) on every rank.  Raises LinAlgError on every
         rank if a pivot is not positive.
@@ -918,6 +944,9 @@ class DistGP:
         _factor_critical_path_first."""
         import time
         t_begin = time.perf_counter()
+        # _ride (fit_predict_resident): my share of the test set's rows K(X*, X) sits below my blocks (and the y rows) and is
+        # carried through every panel solve and update like the y rows
+        self._set_tail(self.v_rows if _ride else 0)
         ops, NB, G, A = self.ops, self.NB, self.G, self.A
         self.sigma, self.ell = float(sigma), float(ell)
         self.have_factor = False
@@ -932,6 +961,10 @@ class DistGP:
         if self.yrow is not None:
             A[self.yrow:self.yrow + YB, :self.Np].zero_()
             A[self.yrow, :self.N].copy_(self.y)
+        if _ride and self.v_rows:
+            v0 = self.rows_base
+            self._cov_cross(self.Xs[self.v_t0:self.v_t0 + max(self.v_cnt, 1)], self.v_cnt, self.X, self.N, 0, self.v_rows, self.Np,
+                            A[v0:v0 + self.v_rows, :self.Np])
         T = self.T
         # panel primitives run beside the update on other streams: their small-LDS forms while the sweep is in flight;
         # switched back on every way out (an exception in a collective must not leave the thread-local flag on)
@@ -1005,6 +1038,7 @@ class DistGP:
             logsum += float(allp[r, 0])
         mtm = float(allp[self.ry, 1])
         self.have_factor = True
+        self._rode = bool(_ride)
         self.stage_ms["fit"] = (time.perf_counter() - t_begin) * 1e3
         return -.5 * mtm - logsum - self.N / 2.0 * math.log(2 * math.pi)
 
@@ -1023,6 +1057,12 @@ class DistGP:
         self.Xk = [self._tensor(self.n_p, self.NB) for _ in range(2)]
         self.dots = self._tensor(2, self.n_p)
         self.m_loc = self._tensor(max(self.nloc, 1) * self.NB)
+        # one-pass form (fit_predict_resident): the test points are dealt to the ranks in contiguous runs of v_nr (a multiple
+        # of 128); mine are v_t0 .. v_t0 + v_cnt (v_rows with the padding to whole 128-row bands)
+        self.v_nr = _round_up((self.n_p + self.G - 1) // self.G, 128)
+        self.v_t0 = min(self.rank * self.v_nr, self.n_p)
+        self.v_rows = min(self.v_nr, self.n_p - self.v_t0)
+        self.v_cnt = max(0, min(self.v_nr, self.n - self.v_t0))
         self.have_test = True
         self.have_v = False
 
@@ -1116,12 +1156,62 @@ class DistGP:
         self.set_test(Xs)
         return self.predict_resident(want_sd)
 
+    def fit_predict_resident(self, sigma, ell, noise_var, want_sd=True):
+        """prediction() in one pass (GP_regression.py:109-156; the single-GPU gpmi_fit_predict_resident): the test points are
+        dealt to the ranks, each rank's rows K(X*_mine, X) ride below its row blocks through the factorisation -- its panel
+        solves and update launches carry them with no launch and NO MESSAGE of their own (the panel column every rank
+        receives for its update is all they need) -- and come out as its rows of v^T; mean and variance of its points are
+        row dots with m (which every rank holds), one all-gather of 2 n / G doubles per rank collects them.  Against
+        predict_resident(): 63 broadcasts of n x nb blocks (2.1 GB per rank at N = 65536, n = 4096, nb = 1024) and the
+        sweep's latency chain are gone.  Returns (lml, mu, sd or var); results agree with factorize() + predict_resident()
+        to rounding.  post_chol() afterwards runs the column-distributed sweep first (it needs v by columns)."""
+        if not self.have_test:
+            raise ValueError("no test set (call set_test)")
+        if self._kind is not None and self._kind[0] == 3 and self.n == self.N and self.G > 1:
+            # kernel_4's delta sits on the diagonal of a SQUARE K_s (CO2_example.py:58): a row offset the cross build
+            # does not take -- the two-call form serves this one case
+            lml = self.factorize(sigma, ell, noise_var)
+            mu, out2 = self.predict_resident(want_sd)
+            return lml, mu, out2
+        import time
+        lml = self.factorize(sigma, ell, noise_var, _ride=True)
+        t_begin = time.perf_counter()
+        ops, G, nr = self.ops, self.G, self.v_nr
+        dots = self._tensor(2, nr)
+        dots.zero_()
+        if self.v_rows:
+            v0 = self.rows_base
+            ops.row_dots(self.A[v0:v0 + self.v_rows], self.Np, self.m, dots[0, :self.v_rows], dots[1, :self.v_rows])
+        if self.coll:
+            alld = self._tensor(G * 2 * nr)
+            self.comm.all_gather(alld, dots.view(-1), tag=("dots_rows",))
+        else:
+            alld = dots
+        alld = alld.view(G, 2, nr).cpu().numpy()
+        mu = np.zeros(G * nr)
+        sq = np.zeros(G * nr)
+        for r in range(G):
+            mu[r * nr:(r + 1) * nr] = alld[r, 0]
+            sq[r * nr:(r + 1) * nr] = alld[r, 1]
+        var = self._kss_diag() - sq[:self.n]
+        self.stage_ms["predict"] = (time.perf_counter() - t_begin) * 1e3
+        with np.errstate(invalid="ignore"):
+            out2 = np.sqrt(var) if want_sd else var
+        return lml, mu[:self.n].copy(), out2
+
+    def fit_predict(self, X, y, Xs, sigma, ell, noise_var, want_sd=True):
+        self.set_train(X, y)
+        self.set_test(Xs)
+        return self.fit_predict_resident(sigma, ell, noise_var, want_sd)
+
     # ------------------------------------------------------------------ posterior covariance factor (f1)
     def post_chol(self, jitter):
         """L_ = cholesky(K_ss + jitter * I - v^T v) (GP_regression.py:153-154) with v distributed: every rank forms
         the contribution of its own column blocks of v^T (one MFMA SYRK), the contributions are summed by one
         all-reduce of n_p x n_p doubles, and every rank factors the small matrix itself (same bits on every
         rank).  Needs predict_resident() first.  Returns the n x n lower factor; raises LinAlgError if not PD."""
+        if self.have_factor and self.have_test and not getattr(self, "have_v", False) and getattr(self, "_rode", False):
+            self.predict_resident()                       # after the one-pass form: v by columns is this sweep's product
         if not (self.have_factor and self.have_test and getattr(self, "have_v", False)):
             raise ValueError("post_chol needs a factorisation and predict_resident() first")
         ops, NB, n_p = self.ops, self.NB, self.n_p

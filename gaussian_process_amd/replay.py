@@ -143,6 +143,14 @@ class ReplayComm:
                 ops.sync()
                 del Vq, mq
             prep["dots"] = dots
+            # one-pass form (tag "dots_rows"): rank q's own test points' v . m and v . v, from the source's results
+            nr = (n_p + G - 1) // G
+            nr = (nr + 127) // 128 * 128
+            kss = gp._kss_diag()
+            rows = torch.zeros(2, G * nr, dtype=torch.float64, device=dev)
+            rows[0, :gp.n].copy_(torch.from_numpy(np.ascontiguousarray(s.mu)).to(dev))
+            rows[1, :gp.n].copy_(torch.from_numpy(np.ascontiguousarray(kss - s.var)).to(dev))
+            prep["dots_rows"] = rows.view(2, G, nr).permute(1, 0, 2).contiguous()
         ops.sync()
         self._prep = prep
         return prep
@@ -204,6 +212,11 @@ class ReplayComm:
             O = flat[:G * n].view(G, 2, n_p)
             O.copy_(prep["dots"])
             O[r].copy_(inp.view(2, n_p))
+        elif kind == "dots_rows":
+            nr = n // 2
+            O = flat[:G * n].view(G, 2, nr)
+            O.copy_(prep["dots_rows"])
+            O[r].copy_(inp.view(2, nr))
         elif kind == "alpha_part":
             k = tag[1]
             O = flat[:G * NB].view(G, NB)

@@ -44,6 +44,8 @@ def main():
     alpha = gp.alpha()
     Lp = gp.post_chol(1e-6)                                       # f1 distributed (GP_regression.py:153-154)
     g_l, g_s = gp.lml_grad()                                      # f2 distributed (tune_hyperparms_regression.py:43-57)
+    # prediction() in one pass: each rank's share of the test rows rides through the factorisation (no message of its own)
+    lml1, mu1, var1 = gp.fit_predict_resident(1.0, 2.0 * np.sqrt(d / 8.0), 5e-4, want_sd=False)
     # the drop-in surface routed to the multi-rank driver (additive dist= / n_gpus= keywords)
     from gaussian_process_amd import GP_regression as G
     from gaussian_process_amd import tune_hyperparms_regression as T
@@ -78,7 +80,7 @@ def main():
     blml, bst = sharded_lml_batch(triples, evaluate)
     np.savez(out + "_rank%d.npz" % rank, lml=lml, mu=mu, var=var, lml2=lml2, mu2=mu2, sd2=sd2, raised=raised,
              blml=blml, bst=bst, triples=triples, alpha=alpha, Lp=Lp, d_mu=d_mu, d_sd=d_sd, d_fp=d_fp, d_lml=d_lml,
-             d_cml=d_cml, g_l=g_l, g_s=g_s)
+             d_cml=d_cml, g_l=g_l, g_s=g_s, lml1=lml1, mu1=mu1, var1=var1)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -66,6 +66,8 @@ def _check(res, oracle, N, d, n):
         assert r["d_cml"] == r["d_lml"]
         assert abs(r["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
         assert np.max(np.abs(r["mu"] - ref["mu"])) <= 1e-9
+        assert r["lml1"] == r["lml"]                      # one pass: the same factor, mean and variance to rounding
+        assert np.max(np.abs(r["mu1"] - ref["mu"])) <= 1e-9 and np.max(np.abs(r["var1"] - ref["var"])) <= 1e-10
         assert np.max(np.abs(r["var"] - ref["var"])) <= 1e-10
         assert np.max(np.abs(r["alpha"] - ref["alpha"])) <= 1e-8 * np.max(np.abs(ref["alpha"]))
         assert abs(r["lml2"] - ref2["lml"]) <= 1e-10 * abs(ref2["lml"])
@@ -138,6 +140,10 @@ def _thread_ranks(world, device, N, d, n, nb, la, oracle, grad=True):
         out["Lp"] = gp.post_chol(1e-6)
         if grad:
             out["g"] = np.array(gp.lml_grad())
+        # prediction() in one pass: every rank's share of the test rows rides through the factorisation below its blocks
+        out["lml1"], out["mu1"], out["var1"] = gp.fit_predict_resident(1.0, ell, 5e-4, want_sd=False)
+        out["alpha1"] = gp.alpha()
+        out["Lp1"] = gp.post_chol(1e-6)                   # needs v by columns: runs the two-call sweep first
         out["lml2"] = gp.factorize(1.3, 1.5 * np.sqrt(d / 8.0), 1e-3)
         out["mu2"], out["sd2"] = gp.predict_resident(want_sd=True)
         try:
@@ -159,6 +165,10 @@ def _thread_ranks(world, device, N, d, n, nb, la, oracle, grad=True):
     assert abs(r0["lml"] - ref["lml"]) <= 1e-10 * abs(ref["lml"])
     assert np.max(np.abs(r0["mu"] - ref["mu"])) <= 1e-9 and np.max(np.abs(r0["var"] - ref["var"])) <= 1e-10
     assert np.max(np.abs(r0["alpha"] - ref["alpha"])) <= 1e-8 * np.max(np.abs(ref["alpha"]))
+    assert r0["lml1"] == r0["lml"] and np.array_equal(r0["alpha1"], r0["alpha"]) and np.array_equal(r0["Lp1"], r0["Lp"])
+    assert np.max(np.abs(r0["mu1"] - ref["mu"])) <= 1e-9 and np.max(np.abs(r0["var1"] - ref["var"])) <= 1e-10
+    assert np.max(np.abs(r0["mu1"] - r0["mu"])) <= 1e-11 * max(1.0, 1e-3 * np.max(np.abs(ref["alpha"])))
+    assert np.max(np.abs(r0["var1"] - r0["var"])) <= 1e-12
     assert abs(r0["lml2"] - ref2["lml"]) <= 1e-10 * abs(ref2["lml"])
     assert np.max(np.abs(r0["mu2"] - ref2["mu"])) <= 1e-9 and np.max(np.abs(r0["sd2"] - np.sqrt(ref2["var"]))) <= 1e-9
     if kbad is not None:

@@ -37,12 +37,18 @@ def _replay_all_ranks(oracle, device, G, N, d, n, nb, la, layout="snake"):
             assert np.max(np.abs(mu - ref["mu"])) <= 1e-9 and np.max(np.abs(var - ref["var"])) <= 1e-10, r
             assert np.max(np.abs(alpha - ref["alpha"])) <= 1e-8 * amax, r
             assert np.max(np.abs(alpha - src.alpha_h)) <= 1e-10 * amax, r
+        # the one-pass form: this rank's test rows ride below its blocks (the same L; its own points' mean and variance are
+        # its own work, the other ranks' come from the source)
+        lml1, mu1, var1 = gp.fit_predict_resident(1.0, ell, 5e-4, want_sd=False)
+        assert lml1 == lml, r
+        assert check_rank(gp, src)["L_rel"] <= 1e-12, r
+        assert np.max(np.abs(mu1 - ref["mu"])) <= 1e-9 and np.max(np.abs(var1 - ref["var"])) <= 1e-10, r
         # the absent ranks' messages had the sizes a real rank receives: per fit, the panel column below every block
         # column minus this rank's own share
         T = src.T
         own = block_layout(T, G, layout)[0]
         want = sum(1 for k in range(T - 1) for b in range(k + 1, T) if own[b] != r)
-        assert gp.comm.bytes["allgather"] == 2 * want * nb * nb * 8, r
+        assert gp.comm.bytes["allgather"] == 3 * want * nb * nb * 8, r          # three fits: the riding rows add no message
 
 
 @pytest.mark.parametrize("G,N,d,n,nb,la,layout", [(2, 700, 3, 50, 128, 2, "snake"), (3, 520, 2, 33, 128, 2, "snake"),
