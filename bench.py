@@ -404,7 +404,7 @@ def run_replay(args):
     torch.cuda.set_device(0)
     wd = Watchdog(0, os.environ.get("GPMI_BENCH_STALL_S", "300"))
     nb_auto = 256
-    while nb_auto < 2048 and N // (2 * nb_auto) >= 8 * G:
+    while nb_auto < 2048 and N // (2 * nb_auto) >= 4 * G:
         nb_auto *= 2
     nb = int(os.environ.get("GPMI_DIST_NB", str(nb_auto)))
     lookahead = int(os.environ.get("GPMI_DIST_LOOKAHEAD", "2"))
@@ -584,11 +584,12 @@ def main():
             dist.init_process_group(backend, timeout=pg_timeout)
         wd.beat("process group up")
         from gaussian_process_amd.dist import DistGP
-        # block rows: as large as leaves every rank >= 8 blocks (balance of the shrinking trailing matrix),
-        # capped at 2048 -- measured with the multi-rank driver on one rank at N=65536: nb 1024 / 2048
-        # = 1.86 / 1.83 s (the update GEMM is more efficient at larger depth, and there are fewer steps)
+        # block rows: as large as leaves every rank >= 4 blocks, capped at 2048 -- the update GEMM is more efficient at
+        # larger depth and there are half the steps to issue; with the balanced dealing 4 blocks per rank still put the
+        # worst rank within 2 % of the mean share (8-rank replay, every rank: 244.4 ms worst at 2048, 247.5 at 1024:
+        # profiles/r04_replay_onepass_G8_nb2048.json)
         nb_auto = 256
-        while nb_auto < 2048 and N // (2 * nb_auto) >= 8 * max(world, 1):
+        while nb_auto < 2048 and N // (2 * nb_auto) >= 4 * max(world, 1):
             nb_auto *= 2
         nb_used = int(os.environ.get("GPMI_DIST_NB", str(nb_auto)))
         gp = DistGP(local_rank, nb=nb_used,
