@@ -657,6 +657,8 @@ class DistGP:
         self.rows = self.rows_base + vrows
         if self.A.shape[0] < max(self.rows, 1):
             self.A = None                                 # free first: a rank's matrix can be most of the memory
+            if self.dev.type == "cuda":
+                torch.cuda.empty_cache()                  # ... and hand the block back, or the allocator keeps it beside the new one
             self.A = self._tensor(max(self.rows, 1), self.ld)
             self.have_factor = False
 

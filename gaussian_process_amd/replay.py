@@ -264,7 +264,9 @@ def check_rank(gp, source: ReplaySource):
     s = source
     NB, G, r = s.NB, gp.G, gp.rank
     out = {"L_rel": 0.0}
-    scale = float(s.gp.A[:s.T * NB, :s.Np].abs().max().item())
+    scale = 0.0                     # block row by block row: the source can be most of the memory, no temporary of its size
+    for b in range(s.T):
+        scale = max(scale, float(s.gp.A[b * NB:(b + 1) * NB, :s.Np].abs().max().item()))
     for li, b in enumerate(gp.my_blocks):
         mine = torch.tril(gp.A[li * NB:(li + 1) * NB, :(b + 1) * NB], diagonal=b * NB)
         ref = torch.tril(s.gp.A[b * NB:(b + 1) * NB, :(b + 1) * NB], diagonal=b * NB)
