@@ -1181,8 +1181,8 @@ def test_fit_predict_one_pass_vs_reference_golden(ctx, name):
     assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
 
 
-@pytest.mark.parametrize("N,d,n", [(1, 1, 1), (130, 2, 1), (300, 1, 37), (2048, 8, 200), (5000, 3, 129), (12500, 8, 700),
-                                   (16384, 8, 1024)])
+@pytest.mark.parametrize("N,d,n", [(1, 1, 1), (130, 2, 1), (300, 1, 37), (200, 2, 700), (2048, 8, 200), (5000, 3, 129),
+                                   (12500, 8, 700), (16384, 8, 1024)])
 def test_fit_predict_one_pass_matches_two_calls(ctx, oracle, N, d, n):
     """same factor (the carried rows do not enter L: LML, m, diagonal and alpha bit for bit), mean and variance to rounding
     (the block widths of the carried rows' sweep are the factorisation's), on both sides of the lookahead threshold; the
@@ -1243,3 +1243,32 @@ def test_fit_predict_one_pass_errors(ctx, oracle):
         mu2, sd2 = c2.predict_resident()
         lml1, mu1, sd1 = c2.fit_predict_resident(1.0, 2.0, 5e-2)
         assert lml1 == lml2 and np.allclose(mu1, mu2, rtol=0, atol=1e-10) and np.allclose(sd1, sd2, rtol=0, atol=1e-10, equal_nan=True)
+
+
+def test_fit_predict_one_pass_other_kernels(ctx):
+    """the reference's other covariance choices ride the same way (prediction(..., 'lin' / 'per'), GP_regression.py:129-136,
+    and CO2_example.py's composite kernel incl. its delta term on a SQUARE K_s): same bits as the two-call form, and the
+    reference's own outputs within the two-call test's tolerances"""
+    g = golden("kernels_lin_per")
+    X, Xs = g["X"], g["Xs"]
+    for kind, p, yk, key in (("lin", (float(g["c"]), 0.0), g["y_lin"], "lin"), ("per", (float(g["p"]), float(g["l"])), g["y_per"], "per")):
+        ctx.set_kernel(kind, *p)
+        try:
+            lml2 = ctx.fit(X, yk, 1.0, 1.0, 5e-4)
+            mu2, sd2 = ctx.predict(Xs)
+            lml1, mu1, sd1 = ctx.fit_predict(X, yk, Xs, 1.0, 1.0, 5e-4)
+        finally:
+            ctx.set_kernel("rbf")
+        assert lml1 == lml2 and np.array_equal(mu1, mu2) and np.array_equal(sd1, sd2, equal_nan=True)
+        assert np.allclose(mu1, g[key + "_mu"], atol=MU_ATOL) and np.allclose(sd1, g[key + "_sd"], atol=SD_ATOL)
+    z = golden("kernels_bo_co2")
+    Xc, yc, th = z["co2_X"], z["co2_y"], z["co2_theta"]
+    ctx.set_kernel("co2", th)
+    try:
+        for Xt in (Xc + 0.37, Xc[:40] + 0.11):           # square K_s (the delta term is live) and a rectangular one
+            lml2 = ctx.fit(Xc, yc, 1.0, 1.0, 5e-4)
+            mu2, var2 = ctx.predict(Xt, want_sd=False)
+            lml1, mu1, var1 = ctx.fit_predict(Xc, yc, Xt, 1.0, 1.0, 5e-4, want_sd=False)
+            assert lml1 == lml2 and np.array_equal(mu1, mu2) and np.array_equal(var1, var2)
+    finally:
+        ctx.set_kernel("rbf")
