@@ -2,7 +2,7 @@
 # Round-4 evidence for profiles/ at the commit it is run on: the bench line (with extra_configs, measured CPU headline,
 # transfer-inclusive step), kernel-trace stats of the bench command, separate PMC passes (FETCH_SIZE, WRITE_SIZE, SQ busy
 # counters) over one step -- never combined with --stats / trace domains beyond --kernel-trace --, and the replays of
-# ranks 0 and G-1 of 8 / 4 / 2.  Run on the GPU box from the repository root:
+# every rank of 8 / 4 / 2.  Run on the GPU box from the repository root:
 #   bash scripts/collect_r04.sh <tag>        (writes gpurun_out/<tag>_*; copy what is to be judged into profiles/)
 set -o pipefail
 TAG=${1:-r04}
@@ -25,8 +25,9 @@ rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_
 python3 scripts/rocpd_extract.py pmc $(find $OUT/prof_tmp/s -name "*.db" | head -1) $OUT/${TAG}_pmc_sq_summary.txt > /dev/null
 echo "sq pass done"
 rm -rf $OUT/prof_tmp
-for G in 8 4 2; do
-  python3 bench.py --replay-rank 0,$((G-1)) --of $G --steps 3 --warmup 1 > $OUT/${TAG}_replay_snake_G$G.json 2> $OUT/${TAG}_replay_G$G.err || exit 1
+for G in 8 4 2; do          # every rank of the G-rank run, one after the other (default layout and call form)
+  RANKS=$(seq -s, 0 $((G-1)))
+  python3 bench.py --replay-rank $RANKS --of $G --steps 3 --warmup 1 > $OUT/${TAG}_replay_G$G.json 2> $OUT/${TAG}_replay_G$G.err || exit 1
 done
 echo "replays done"
 cat $OUT/${TAG}_kernel_stats_top.txt | head -12; cat $OUT/${TAG}_roofline_traffic.json
