@@ -265,8 +265,8 @@ def check_rank(gp, source: ReplaySource):
     NB, G, r = s.NB, gp.G, gp.rank
     out = {"L_rel": 0.0}
     scale = 0.0                     # block row by block row: the source can be most of the memory, no temporary of its size
-    for b in range(s.T):
-        scale = max(scale, float(s.gp.A[b * NB:(b + 1) * NB, :s.Np].abs().max().item()))
+    for b in range(s.T):            # ... and the lower triangle only: above it the buffer holds whatever the allocation held
+        scale = max(scale, float(torch.tril(s.gp.A[b * NB:(b + 1) * NB, :(b + 1) * NB], diagonal=b * NB).abs().max().item()))
     for li, b in enumerate(gp.my_blocks):
         mine = torch.tril(gp.A[li * NB:(li + 1) * NB, :(b + 1) * NB], diagonal=b * NB)
         ref = torch.tril(s.gp.A[b * NB:(b + 1) * NB, :(b + 1) * NB], diagonal=b * NB)
