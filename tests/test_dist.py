@@ -456,11 +456,13 @@ def test_bench_two_ranks_through_the_self_spawn_path():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["config"]["partition"] == "row-block cyclic x2"
     assert out["value"] > 0 and np.isfinite(out["lml"]) and len(out["per_rank_ms"]) == 2
-    # the same problem on the single-GPU path: same log-marginal-likelihood to 1e-12 relative
+    # the same problem on the single-GPU path: the same log-marginal-likelihood to the path's LML tolerance (the two
+    # factorisations block differently -- 512 rows per block here, 512-column panels there -- and the LML is a sum of
+    # cancelling terms a hundred times its size: 4e-12 relative measured)
     p1 = _bench(["--gpus", "1", "--size", "8192", "--ntest", "512", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {})
     assert p1.returncode == 0, p1.stderr[-3000:]
     one = json.loads([l for l in p1.stdout.splitlines() if l.startswith("{")][0])
-    assert abs(one["lml"] - out["lml"]) <= 1e-12 * abs(one["lml"])
+    assert abs(one["lml"] - out["lml"]) <= 1e-10 * abs(one["lml"])
     # the bench contract's keys on the single-GPU line (roofline blocks of the trailing update, a1+a2, a5, a7)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "targets", "kbuild_hbm", "alpha_hbm", "solve_v_mfma",
@@ -468,6 +470,11 @@ def test_bench_two_ranks_through_the_self_spawn_path():
         assert key in one, key
     assert one["dtype"] == "f64" and one["config"]["workload"] and one["roofline"]["bound"] == "mfma"
     assert 0 < one["alpha_hbm"]["frac"] < 1 and 0 < one["solve_v_mfma"]["frac"] < 1
+    # the step is prediction() in one pass; the two-call form is timed beside it and gives the same bits
+    assert one["config"]["call_form"].startswith("one pass") and out["config"]["call_form"].startswith("one pass")
+    oc = one["other_call_form"]
+    assert oc["form"].startswith("two calls") and oc["ms_per_step"] > 0
+    assert oc["lml_equal"] and oc["alpha_equal"] and oc["max_abs_dmu"] == 0.0 and oc["max_abs_dvar"] == 0.0
 
 
 @pytest.mark.gpu
