@@ -501,6 +501,9 @@ def main():
     ap.add_argument("--dim", type=int, default=8)
     ap.add_argument("--ntest", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-form", action="store_true",
+                    help="do not time the other call form after the timed region (profiling passes: every launch of the run "
+                         "then belongs to the timed form)")
     ap.add_argument("--no-extra-configs", action="store_true",
                     help="skip the other BASELINE configs (2, 5 and 4's workload on one GPU) behind the headline steps")
     ap.add_argument("--replay-rank", default=None,
@@ -726,7 +729,7 @@ def main():
     flops = algorithmic_flops(N, n)
     value = flops / (dt / args.steps) / 1e12
     other_form = None
-    if not multi:
+    if not multi and not args.no_other_form:
         # the other call form, outside the timed region: its wall, its results against the timed form's, and -- from the
         # two-call form, where a7 runs alone -- the stage timers of the predict sweep
         other = step_two if one_pass else step_one
