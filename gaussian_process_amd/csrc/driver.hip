@@ -122,7 +122,7 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
     const std::vector<int64_t> widths = block_schedule(c, ncols);
     const int64_t NB = c->block(ncols);
     // below ~12k columns the two-stream choreography costs more than the panel it hides
-    const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= 12288;
+    const bool la = c->lookahead && c->pstream && ncols > NB && ncols >= c->la_min;
     hipStream_t sp_ = la ? c->pstream : sm;
     // panel kernels beside the trailing update use their small-LDS forms -- while there IS a trailing update of some length
     // to run beside: once the columns right of the panel are fewer than c->shallow_min, part (b) of a step is over long
@@ -426,7 +426,7 @@ hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri)
     const double* A = c->A.as<double>();
     const int64_t ld = c->ldA, Np = c->Np;
     const int64_t NB = c->block(Np);
-    const bool la = c->lookahead && c->pstream && Np > NB && Np >= 12288;
+    const bool la = c->lookahead && c->pstream && Np > NB && Np >= c->la_min;
     hipStream_t sp_ = la ? c->pstream : sm;
     // small-LDS panel forms beside the update only for sweeps with enough rows to keep the chip busy: for a few
     // hundred test points the chain of launches is what counts, and the one-launch trsm128 is shorter

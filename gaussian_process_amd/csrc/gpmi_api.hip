@@ -136,6 +136,9 @@ int gpmi_set_option(gpmi_ctx* c, const char* name, int64_t value) {
         c->timing = value ? 1 : 0;
     } else if (!strcmp(name, "lookahead")) {
         c->lookahead = value ? 1 : 0;
+    } else if (!strcmp(name, "la_min")) {
+        if (value < 0) return fail_arg("la_min must be >= 0");
+        c->la_min = value;
     } else if (!strcmp(name, "shallow_min")) {
         if (value < 0) return fail_arg("shallow_min must be >= 0");
         c->shallow_min = value;
@@ -667,7 +670,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
 // 0.45 -> 0.24 ms, N = 2048 1.74 -> 0.93 ms, N = 8192 10.5 -> 6.9 ms, N = 16384 39.5 -> 32.1 ms,
 // N = 32768 213 -> 201 ms).
 static int lane_prepare(gpmi_ctx* c, gpmi_ctx* l) {
-    l->nb = c->nb; l->ld_pad = c->ld_pad; l->lookahead = c->lookahead; l->ramp = c->ramp; l->timing = c->timing;
+    l->nb = c->nb; l->ld_pad = c->ld_pad; l->lookahead = c->lookahead; l->la_min = c->la_min; l->ramp = c->ramp; l->timing = c->timing;
     l->tune = c->tune;
     l->kind = c->kind; l->kp0 = c->kp0; l->kp1 = c->kp1;
     for (int i = 0; i < 11; ++i) l->kpv[i] = c->kpv[i];
@@ -688,11 +691,22 @@ int gpmi_lml_batch(gpmi_ctx* c, const double* triples, int64_t T, double* lml_ou
     if (!c->have_train) return fail_arg("gpmi_lml_batch: no training set (call gpmi_set_train)");
     HIP_TRY(hipSetDevice(c->device));
     const int64_t Np = round_up(c->N, TILE);
-    // two lanes; more do not help the small sizes (measured, 12 triples: N = 512 0.45 / 0.24 / 0.38 / 0.31 ms per triple with
-    // 1 / 2 / 3 / 4 lanes, unchanged with GPU_MAX_HW_QUEUES=8); three from the lookahead threshold up (N = 32768, round 4:
-    // 0.1934 / 0.1865 / 0.1849 / 0.1855 s per triple with 1 / 2 / 3 / 4 lanes, profiles/r04_cfg5_lanes.txt)
-    int L = c->lanes ? c->lanes : (Np > 32768 ? 1 : Np >= 12288 ? 3 : 2);
+    // lanes by size, measured with 24 triples per call (round 4, profiles/r04_lml_batch_lanes_small.txt; ms per triple with
+    // 2 / 3 / 4 / 5 / 6 lanes): N = 512 0.159 / 0.112 / 0.092 / 0.161 / 0.163, 2048 0.572 / 0.408 / 0.322 / 0.468 / 0.505,
+    // 8192 5.21 / 4.46 / 4.13 / 4.85 / 4.75 -- four single-stream lanes below the lookahead threshold (round 2's "two, more
+    // do not help" was measured with four hardware queues; _lib.py now asks for eight); 12288 12.6 / 12.4 / 12.1 / 11.8 /
+    // 11.8 and 16384 26.5 / 25.3 / 26.2 / 24.8 / 24.8 -- five there; N = 32768 (profiles/r04_cfg5_lanes.txt) 0.1934 / 0.1865 /
+    // 0.1849 / 0.1855 s with 1 / 2 / 3 / 4 -- three
+    int L = c->lanes ? c->lanes : (Np > 32768 ? 1 : Np >= 24576 ? 3 : Np >= 12288 ? 5 : 4);
     L = (int)std::min<int64_t>(L, std::max<int64_t>(T, 1));
+    // lanes beside each other fill the chip themselves: below 12288 columns every lane runs on ONE stream (a lane's
+    // lookahead would add a second stream per lane and loses: N = 8192, 3 lanes 4.46 ms per triple without, 5.45 with;
+    // profiles/r04_la_min_batch.txt), whatever the threshold of this context's single fits
+    struct LaMinScope {
+        gpmi_ctx* c; int64_t keep;
+        ~LaMinScope() { c->la_min = keep; }
+    } la_scope{c, c->la_min};
+    if (L > 1) c->la_min = std::max<int64_t>(c->la_min, 12288);
     while ((int)c->lane_ctx.size() < L - 1) {
         gpmi_ctx* l = nullptr;
         int rc = gpmi_ctx_create(c->device, &l);

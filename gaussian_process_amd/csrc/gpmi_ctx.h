@@ -103,6 +103,9 @@ struct gpmi_ctx {
     int64_t ld_pad = 544;   // doubles added to every leading dimension
     int timing = 1;
     int lookahead = 1;      // factor panel k+1 while the rest of trailing update k runs
+    int64_t la_min = 6144;  // ... from this many columns on (below, the two-stream choreography costs more than the panel it hides:
+                            // profiles/r04_la_min_sweep.txt -- one pass / two calls / fit alone at N = 4096: 3.06 -> 2.96 / 3.82 -> 3.86 /
+                            // 2.56 -> 2.59 ms, 6144: 5.41 -> 5.20 / 6.69 -> 6.50 / 4.67 -> 4.48, 10240: 13.8 -> 12.6 / 15.9 -> 14.7; same bits)
     int64_t shallow_min = 6144; // under lookahead, panels with fewer columns left than this use the one-launch panel kernels (0: never)
     int one_pass_form = 0;  // gpmi_fit_predict_resident: 1 the test set's rows ride in the panel and update launches, 2 they follow on a
                             // stream of their own (panel k done -> their solve against L_kk -> their update), 0 = by size

@@ -67,7 +67,9 @@ int gpmi_ctx_create(int device, gpmi_ctx** out);
 int gpmi_ctx_destroy(gpmi_ctx* ctx);
 /* tuning knobs; unknown names -> GPMI_ERR_BAD_ARG.
  * per context:  "nb" (outer Cholesky block, 0 = by size), "ld_pad" (doubles added to leading dimensions),
- *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "lanes" (factorisations in flight in
+ *               "timing" (0/1: hipEvent stage timers), "lookahead" (0/1), "la_min" (columns from which lookahead is used,
+ *               default 12288), "one_pass_form" (gpmi_fit_predict_resident: 0 by size, 1 the test rows ride inside the
+ *               panel and update launches, 2 they follow on a stream of their own), "lanes" (factorisations in flight in
  *               gpmi_lml_batch, 0 = by size), "ramp" (bit mask, default 0: 1 block widths ramp up at the start of the
  *               sweep, 2 half width over the last blocks, 4 quarter width for the last one, bits 4.. = how many blocks
  *               count as "last" (0: three), when "nb" is automatic.  Until round 2 any non-zero value meant "up and
