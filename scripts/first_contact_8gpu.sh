@@ -35,4 +35,6 @@ timeout -k 10 560 python3 bench.py --gpus $NG --steps 3 --warmup 1 > $OUT/4_benc
 cut -c1-400 $OUT/4_bench_gN.json
 GPMI_DIST_COMM=rccl timeout -k 10 560 python3 bench.py --gpus $NG --steps 3 --warmup 1 > $OUT/4b_bench_gN_cabi.json 2> $OUT/4b_bench_gN_cabi.err \
     && cut -c1-400 $OUT/4b_bench_gN_cabi.json || say "the C-ABI backend at full size failed (see $OUT/4b_bench_gN_cabi.err)"
+GPMI_BENCH_TWO_CALLS=1 timeout -k 10 560 python3 bench.py --gpus $NG --steps 3 --warmup 1 > $OUT/4c_bench_gN_two_calls.json 2> $OUT/4c_bench_gN_two_calls.err \
+    && cut -c1-400 $OUT/4c_bench_gN_two_calls.json || say "the two-call step (A/B of the one-pass step; column-wise predict with its n x nb broadcasts) failed (see $OUT/4c_bench_gN_two_calls.err)"
 say "all four stages passed"
