@@ -1272,3 +1272,28 @@ def test_fit_predict_one_pass_other_kernels(ctx):
             assert lml1 == lml2 and np.array_equal(mu1, mu2) and np.array_equal(var1, var2)
     finally:
         ctx.set_kernel("rbf")
+
+
+@pytest.mark.parametrize("N,n", [(3000, 100), (7000, 300), (9000, 64)])
+def test_lookahead_threshold_does_not_change_the_bits(ctx, oracle, N, n):
+    """option la_min (round 4: lookahead from 6144 columns, 12288 before): the two-stream choreography splits the update
+    launches, never a sum -- LML, alpha, mean and variance bit for bit with lookahead forced on, off and by default, as one
+    pass and as two calls, at ragged sizes on both sides of the threshold"""
+    X, y, Xs = oracle.synthetic_problem(N, 5, n, seed=23)
+    out = []
+    for la_min in (1 << 30, 1024, 6144):
+        ctx.set_option("la_min", la_min)
+        try:
+            lml1, mu1, var1 = ctx.fit_predict(X, y, Xs, 1.0, 1.7, 5e-4, want_sd=False)
+            a1 = ctx.alpha()
+            lml2 = ctx.factorize(1.0, 1.7, 5e-4)
+            mu2, var2 = ctx.predict_resident(want_sd=False)
+            out.append((lml1, mu1, var1, a1, lml2, mu2, var2, ctx.alpha()))
+        finally:
+            ctx.set_option("la_min", 6144)
+    for o in out:
+        assert o[0] == out[0][0] == o[4]
+        for i in (1, 2, 3):
+            assert np.array_equal(o[i], out[0][i]) and np.array_equal(o[i + 4], out[0][i])
+    ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 1.7, 5e-4)
+    assert np.max(np.abs(out[0][1] - ref["mu"])) <= MU_ATOL and abs(out[0][0] - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
