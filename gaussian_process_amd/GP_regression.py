@@ -112,10 +112,10 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
     ctx = ctx or default_context()
     try:
         sg, ll = _select_kernel(ctx, kernel_choice, l, sigma)  # :125-136
-        # :126-127, 138-148 in one pass: K(X*, X) rides through the Cholesky below the y row (gpmi_fit_predict_resident)
-        lml, mu_post, stand_devi = ctx.fit_predict(X_train, y_train, X_test, sg, ll, noise_var, want_sd=True)
+        # :126-128, 138-148 and 153-154 in one pass: ONE Cholesky of [[K + sI, .], [K(X*, X), K_ss + jitter I]] -- the test
+        # rows ride through it below the training rows, and its last n columns are L_ (gpmi_fit_predict_sample_resident)
+        lml, mu_post, stand_devi, L_ = ctx.fit_predict_sample(X_train, y_train, X_test, sg, ll, noise_var, jitter, want_sd=True)
         n = mu_post.shape[0]
-        L_ = ctx.post_chol(jitter)                            # :154
     finally:
         ctx.set_kernel('rbf')
     f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(n, num_fun)))  # :155

@@ -250,10 +250,12 @@ void set_kernel_args(const gpmi_ctx* c, RbfArgs& r) {
     for (int i = 0; i < 11; ++i) r.kpv[i] = c->kpv[i];
 }
 
-int ensure_train_buffers(gpmi_ctx* c, int64_t test_rows) {
+int ensure_train_buffers(gpmi_ctx* c, int64_t test_rows, bool test_cols) {
     c->Np = round_up(c->N, TILE);
-    c->ldA = c->Np + c->ld_pad;
+    c->ldA = c->Np + (test_cols ? test_rows : 0) + c->ld_pad;
     c->Mp = c->Np + TILE + test_rows;
+    c->yrow = test_cols ? c->Np + test_rows : c->Np;         // with their own columns the test rows come BEFORE the y rows
+    c->post_in_A = false;
     HIP_TRY(c->A.ensure((size_t)c->Mp * c->ldA * sizeof(double)));
     HIP_TRY(c->info.ensure(sizeof(int64_t)));
     HIP_TRY(c->red.ensure(16 * sizeof(double)));
@@ -286,7 +288,7 @@ void meanvar_to_host(gpmi_ctx* c, const std::vector<double>& h, double* mu, doub
 
 // K build + Cholesky (+ forward solve through the y row) + LML on the stream
 int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml,
-                   int64_t* bad_pivot, bool with_test, double* mu, double* out2, int want_sd) {
+                   int64_t* bad_pivot, bool with_test, double* mu, double* out2, int want_sd, bool with_post, double jitter) {
     if (!c->have_train) return fail_arg("gpmi_factorize: no training set (call gpmi_set_train)");
     if (c->kind == 0 && (!(ell != 0.0) || std::isnan(ell) || std::isnan(sigma)))
         return fail_arg("gpmi_factorize: ell must be non-zero and hyper-parameters finite");
@@ -299,13 +301,15 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
         // 8.74, 16384 37.5 / 34.9 / 34.9, 32768 262.7 / 257.9 / 256.7, 65536 1702 / 1698 / 1710 -- the chip is work-conserving
         // either way, and riding costs no launches: the default at every size
         form = c->one_pass_form ? c->one_pass_form : 1;
+        if (with_post) form = 3;                   // the augmented matrix: the rows ride (there is no other way) with columns of their own
         if (form == 2 && !c->vstream) {
             int lo = 0, hi = 0;
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             HIP_TRY(hipStreamCreateWithPriority(&c->vstream, hipStreamNonBlocking, lo));
         }
     }
-    int rc = ensure_train_buffers(c, with_test ? c->np_ : 0);
+    if (with_post && std::isnan(jitter)) return fail_arg("gpmi_fit_predict_sample: jitter is NaN");
+    int rc = ensure_train_buffers(c, with_test ? c->np_ : 0, form == 3);
     if (rc) return rc;
     hipStream_t s = c->stream;
     c->have_factor = false;
@@ -334,9 +338,11 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
     HIP_TRY(launch_rbf(s, r));
     c->span_end(sp);                  // GPMI_T_KBUILD is the kernel-matrix build (a1 + a2) alone
     // the augmented rows: y then zeros (a4 rides in the factorisation)
-    HIP_TRY(launch_fill_rows(s, A + c->Np * c->ldA, c->ldA, TILE, c->Np, 0.0));
-    HIP_TRY(launch_set_yrow(s, A + c->Np * c->ldA, c->y.as<double>(), c->N, c->Np));
-    double* Vr = A + (c->Np + TILE) * c->ldA;
+    const int64_t ncols = c->Np + (form == 3 ? c->np_ : 0);   // columns of the factorisation
+    HIP_TRY(launch_fill_rows(s, c->m_row(), c->ldA, TILE, ncols, 0.0));
+    HIP_TRY(launch_set_yrow(s, c->m_row(), c->y.as<double>(), c->N, c->Np));
+    c->v_row0 = form == 3 ? c->Np : c->Np + TILE;
+    double* Vr = A + c->v_row0 * c->ldA;
     if (with_test) {                  // K(X*, X) below the y rows (a1 for K_s, GP_regression.py:127): they leave as v^T
         sp = c->span_begin(GPMI_T_KS);
         RbfArgs t;
@@ -348,6 +354,16 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
         t.max_sq = box_max_sq(c->boxXs, c->boxX);
         t.out = Vr; t.ld = c->ldA;
         HIP_TRY(launch_rbf(s, t));
+        if (form == 3) {              // K_ss + jitter I in the rows' own columns, lower tiles (GP_regression.py:128, 154)
+            RbfArgs q;
+            q.A = q.B = c->Xs.as<double>();
+            q.nA = q.nB = c->n; q.d = c->d; q.row0 = 0; q.nrows = c->np_; q.ncols = c->np_;
+            set_kernel_args(c, q);
+            q.diag_add = jitter; q.symmetric = 1; q.delta_square = 1;
+            q.max_sq = box_max_sq(c->boxXs, c->boxXs);
+            q.out = Vr + c->Np; q.ld = c->ldA;
+            HIP_TRY(launch_rbf(s, q));
+        }
         c->span_end(sp);
     }
 
@@ -360,13 +376,15 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
         HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Np + TILE, c->info.as<int64_t>(), true, 0, &f));
         c->span_end(spv, f.vs);
         HIP_TRY(c->order(f.vs, s));
+    } else if (form == 3) {
+        HIP_TRY(cholesky_inplace(c, A, c->ldA, ncols, c->Mp, c->info.as<int64_t>(), true, 0));
     } else {
         HIP_TRY(cholesky_inplace(c, A, c->ldA, c->Np, c->Mp, c->info.as<int64_t>(), true, with_test ? c->n : 0));
     }
     c->span_end(sp);
 
     sp = c->span_begin(GPMI_T_LML);
-    HIP_TRY(launch_lml_reduce(s, A, c->ldA, A + c->Np * c->ldA, c->N, c->red.as<double>()));
+    HIP_TRY(launch_lml_reduce(s, A, c->ldA, c->m_row(), c->N, c->red.as<double>()));
     c->span_end(sp);
 
     std::vector<double> h;
@@ -374,7 +392,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
         HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
         sp = c->span_begin(GPMI_T_MEANVAR);
         double* dot = c->vec.as<double>();
-        HIP_TRY(launch_row_dots(s, Vr, c->ldA, c->np_, c->Np, A + c->Np * c->ldA, dot, dot + c->np_));
+        HIP_TRY(launch_row_dots(s, Vr, c->ldA, c->np_, c->Np, c->m_row(), dot, dot + c->np_));
         c->span_end(sp);
         h.resize(2 * (size_t)c->np_);
         HIP_TRY(hipMemcpyAsync(h.data(), dot, h.size() * 8, hipMemcpyDeviceToHost, s));
@@ -395,8 +413,10 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
             return fail_runtime(hipErrorUnknown, "gpmi_factorize: the resident potrf128 server did not answer (option potrf_server)");
         }
     }
-    if (info != big && info < c->N) {
-        if (bad_pivot) *bad_pivot = info + 1;
+    if (info != big && (info < c->N || (form == 3 && info >= c->Np && info < c->Np + c->n))) {
+        // a pivot of K + sI (GP_regression.py:138) or, in the augmented form, of the posterior covariance (:154; counted from
+        // its own first column, as gpmi_post_chol reports it)
+        if (bad_pivot) *bad_pivot = info < c->N ? info + 1 : info - c->Np + 1;
         if (lml) *lml = std::numeric_limits<double>::quiet_NaN();
         g_err = "Matrix is not positive definite";
         return GPMI_ERR_NOT_PD;
@@ -410,6 +430,8 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
         c->v_in_A = true;
         c->ldV = c->ldA;
         c->have_v = true;
+        c->post_in_A = form == 3;
+        c->post_jitter = jitter;
         meanvar_to_host(c, h, mu, out2, want_sd);
     }
     return GPMI_OK;

@@ -321,7 +321,7 @@ int gpmi_get_m(gpmi_ctx* c, double* m_out) {
     if (!c || !m_out) return fail_arg("gpmi_get_m: null argument");
     if (!c->have_factor) return fail_arg("gpmi_get_m: no factorisation resident");
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(m_out, c->A.as<double>() + c->Np * c->ldA, (size_t)c->N * 8,
+    HIP_TRY(hipMemcpyAsync(m_out, c->m_row(), (size_t)c->N * 8,
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return GPMI_OK;
@@ -384,7 +384,7 @@ int gpmi_get_alpha(gpmi_ctx* c, double* alpha_out) {
     HIP_TRY(c->vec.ensure((size_t)std::max(c->Np, c->np_) * 4 * 8));
     double* x = c->vec.as<double>();
     // padded tail of m is zero (identity padding), so the padded system stays consistent
-    HIP_TRY(hipMemcpyAsync(x, c->A.as<double>() + c->Np * c->ldA, (size_t)c->Np * 8,
+    HIP_TRY(hipMemcpyAsync(x, c->m_row(), (size_t)c->Np * 8,
                            hipMemcpyDeviceToDevice, s));
     size_t sp = c->span_begin(GPMI_T_ALPHA);
     if (c->factor_fused) {
@@ -457,7 +457,7 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     sp = c->span_begin(GPMI_T_MEANVAR);
     double* dot = c->vec.as<double>();
     double* sq = dot + c->np_;
-    HIP_TRY(launch_row_dots(s, V, c->ldV, c->np_, c->Np, c->A.as<double>() + c->Np * c->ldA, dot, sq));
+    HIP_TRY(launch_row_dots(s, V, c->ldV, c->np_, c->Np, c->m_row(), dot, sq));
     c->span_end(sp);
 
     std::vector<double> h(2 * (size_t)c->np_);
@@ -481,6 +481,23 @@ int gpmi_fit_predict_resident(gpmi_ctx* c, double sigma, double ell, double nois
     HIP_TRY(hipSetDevice(c->device));
     TuneScope tune_scope(&c->tune);
     return factorize_impl(c, sigma, ell, noise_var, lml, bad_pivot, true, mu, out2, want_sd);
+}
+
+// prediction() WITH its posterior-sample factor in one pass (a11 + f1, GP_regression.py:109-156): one Cholesky of the augmented
+//     [[K + sI, .], [K(X*, X), K_ss + jitter I]]        (N + n columns; the y rows ride below)
+// -- its first N columns are L, the test rows' first N columns v^T, and its last n columns cholesky(K_ss + jitter I - v^T v):
+// the Schur complement the trailing updates leave there IS the posterior covariance.  Same flops as the three separate steps
+// ((N + n)^3 / 3), no SYRK launch and no second factorisation.  L_out (n x n row-major, zeros above the diagonal) may be
+// null: gpmi_post_chol with the same jitter then only downloads it.
+int gpmi_fit_predict_sample_resident(gpmi_ctx* c, double sigma, double ell, double noise_var, double jitter, double* lml,
+                                     int64_t* bad_pivot, double* mu, double* out2, int want_sd, double* L_out) {
+    if (!c) return fail_arg("gpmi_fit_predict_sample: null context");
+    if (!c->have_test) return fail_arg("gpmi_fit_predict_sample: no test set (call gpmi_set_test)");
+    HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
+    int rc = factorize_impl(c, sigma, ell, noise_var, lml, bad_pivot, true, mu, out2, want_sd, true, jitter);
+    if (rc || !L_out) return rc;
+    return gpmi_post_chol(c, jitter, L_out, bad_pivot);
 }
 
 int gpmi_predict(gpmi_ctx* c, const double* Xs, int64_t n, double* mu, double* out2, int want_sd) {
@@ -511,7 +528,7 @@ int gpmi_lml_grad(gpmi_ctx* c, double* d_ell, double* d_sigma) {
     size_t sp = c->span_begin(GPMI_T_GRAD);
     // alpha = L^-T m (a5)
     double* alpha = c->vec.as<double>();
-    HIP_TRY(hipMemcpyAsync(alpha, c->A.as<double>() + Np * ld, (size_t)Np * 8, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(alpha, c->m_row(), (size_t)Np * 8, hipMemcpyDeviceToDevice, s));
     if (c->factor_fused) {
         HIP_TRY(backward_solve_fused(c, alpha, alpha + Np));
         alpha += Np;
@@ -627,6 +644,15 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     hipStream_t s = c->stream;
     c->timers_reset({GPMI_T_POSTCHOL});
     const int64_t np_ = c->np_, n = c->n;
+    if (c->post_in_A && c->v_in_A && jitter == c->post_jitter) {
+        // the factor rode through the augmented factorisation (gpmi_fit_predict_sample_resident): it sits behind L
+        HIP_TRY(c->dense.ensure((size_t)n * n * 8));
+        HIP_TRY(launch_extract(s, c->A.as<double>() + c->Np * c->ldA + c->Np, c->ldA, 0, n, 0, n, c->dense.as<double>(), 1));
+        HIP_TRY(hipMemcpyAsync(L_out, c->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (bad_pivot) *bad_pivot = 0;
+        return GPMI_OK;
+    }
     c->ldP = np_ + 32;
     HIP_TRY(c->P.ensure((size_t)np_ * c->ldP * 8));
     double* P = c->P.as<double>();

@@ -132,8 +132,15 @@ struct gpmi_ctx {
     // test set
     int64_t n = 0, np_ = 0, ldV = 0, ldP = 0;
     bool have_test = false, have_v = false;
-    bool v_in_A = false;     // v^T is resident in the rows of A below the y rows (gpmi_fit_predict_resident), not in V
-    double* v_rows() { return v_in_A ? A.as<double>() + (Np + 128) * ldA : V.as<double>(); }
+    bool v_in_A = false;     // v^T is resident in rows of A (gpmi_fit_predict_resident: from row v_row0), not in V
+    int64_t v_row0 = 0;
+    double* v_rows() { return v_in_A ? A.as<double>() + v_row0 * ldA : V.as<double>(); }
+    // the y rows: row Np of A -- or, when the posterior factor rides as well (gpmi_fit_predict_sample_resident), behind the
+    // test rows, whose own n_p columns then follow the training columns
+    int64_t yrow = 0;
+    double* m_row() { return A.as<double>() + yrow * ldA; }
+    bool post_in_A = false;  // A[Np.., Np..] holds cholesky(K_ss + post_jitter I - v^T v) of the resident test set
+    double post_jitter = 0.0;
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;
@@ -213,11 +220,14 @@ hipError_t cholesky_inplace(gpmi_ctx* c, double* A, int64_t ld, int64_t ncols, i
                             bool account, int64_t carried_rows = 0, const SweepFollower* follow = nullptr);
 hipError_t solve_sweep(gpmi_ctx* c, double* V, int64_t ldv, int64_t m, bool tri = false);
 void set_kernel_args(const gpmi_ctx* c, RbfArgs& r);
-int ensure_train_buffers(gpmi_ctx* c, int64_t test_rows = 0);
+int ensure_train_buffers(gpmi_ctx* c, int64_t test_rows = 0, bool test_cols = false);
 // with_test: the test set's rows K(X*, X) ride below the y rows (they come out as v^T = K_s^T L^-T, a7 inside a3) and
 // mean / variance (a6, a8) are read off them behind the LML
+// with_post (needs with_test): the test rows also get their own columns K_ss + jitter I, i.e. ONE Cholesky of
+//   [[K + sI, .], [K_s^T, K_ss + jitter I]]  (N + n columns)  --  its last n columns are cholesky(K_ss + jitter I - v^T v), f1
 int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot,
-                   bool with_test = false, double* mu = nullptr, double* out2 = nullptr, int want_sd = 1);
+                   bool with_test = false, double* mu = nullptr, double* out2 = nullptr, int want_sd = 1,
+                   bool with_post = false, double jitter = 0.0);
 void meanvar_to_host(gpmi_ctx* c, const std::vector<double>& h, double* mu, double* out2, int want_sd);
 
 }  // namespace gpmi

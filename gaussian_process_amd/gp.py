@@ -217,6 +217,26 @@ class GPContext:
         check(st, bad.value)
         return lml.value, mu, o2
 
+    def fit_predict_sample_resident(self, sigma, l, noise_var, jitter, want_sd=True):
+        """prediction() with its posterior-sample factor in one pass (GP_regression.py:109-156): ONE Cholesky of
+        [[K + sI, .], [K(X*, X), K_ss + jitter I]] -- L, v^T and L_ = cholesky(K_ss + jitter I - v^T v) are its blocks.
+        Returns (lml, mu, sd_or_var, L_)."""
+        lml = C.c_double()
+        bad = C.c_int64()
+        mu = np.empty(self.n)
+        o2 = np.empty(self.n)
+        L_ = np.empty((self.n, self.n))
+        st = self._lib.gpmi_fit_predict_sample_resident(self._h, scalar(sigma, "sigma"), scalar(l, "l"), scalar(noise_var, "noise_var"),
+                                                        float(jitter), C.byref(lml), C.byref(bad), ptr(mu), ptr(o2),
+                                                        1 if want_sd else 0, ptr(L_))
+        check(st, bad.value)
+        return lml.value, mu, o2, L_
+
+    def fit_predict_sample(self, X, y, Xs, sigma, l, noise_var, jitter, want_sd=True):
+        self.set_train(X, y)
+        self.set_test(Xs)
+        return self.fit_predict_sample_resident(sigma, l, noise_var, jitter, want_sd)
+
     def fit_predict(self, X, y, Xs, sigma, l, noise_var, want_sd=True):
         self.set_train(X, y)
         self.set_test(Xs)

@@ -160,6 +160,16 @@ int gpmi_predict(gpmi_ctx* ctx, const double* Xs, int64_t n, double* mu, double*
 int gpmi_fit_predict_resident(gpmi_ctx* ctx, double sigma, double ell, double noise_var, double* lml, int64_t* bad_pivot,
                               double* mu, double* out2, int want_sd);
 
+/* ... and with the posterior-sample factor of GP_regression.py:154 in the same pass: one Cholesky of the augmented matrix
+ *   [[K + sI, .], [K(X*, X), K_ss + jitter I]]   (N + n columns, the y rows below): its last n columns are
+ *   L_ = cholesky(K_ss + jitter I - v.T @ v), the Schur complement the trailing updates leave there.  Arguments as
+ * gpmi_fit_predict_resident plus jitter and L_out (n x n row-major, zeros above the diagonal; may be NULL -- gpmi_post_chol
+ * with the same jitter then only downloads it).  GPMI_ERR_NOT_PD for a pivot of K + sI (:138) or of the posterior covariance
+ * (:154; bad_pivot then counts from the posterior's own first column).  LML, alpha, mean and variance as the other forms to
+ * rounding (the leading dimension and the block boundaries differ); L_ as gpmi_post_chol to rounding. */
+int gpmi_fit_predict_sample_resident(gpmi_ctx* ctx, double sigma, double ell, double noise_var, double jitter, double* lml,
+                                     int64_t* bad_pivot, double* mu, double* out2, int want_sd, double* L_out);
+
 /* L_ = cholesky(K_ss + jitter*I - v.T @ v)            GP_regression.py:154
  * for the test set of the last predict; L_out: n x n row-major, zeros above the
  * diagonal.   */

@@ -1297,3 +1297,75 @@ def test_lookahead_threshold_does_not_change_the_bits(ctx, oracle, N, n):
             assert np.array_equal(o[i], out[0][i]) and np.array_equal(o[i + 4], out[0][i])
     ref = oracle.fit_predict_feasible(X, Xs, y, 1.0, 1.7, 5e-4)
     assert np.max(np.abs(out[0][1] - ref["mu"])) <= MU_ATOL and abs(out[0][0] - ref["lml"]) <= LML_RTOL * abs(ref["lml"])
+
+
+# ---- prediction() WITH its posterior-sample factor in one pass: the augmented Cholesky (gpmi_fit_predict_sample_resident) ----
+@pytest.mark.parametrize("name", golden_names())
+def test_fit_predict_sample_one_pass_vs_reference_golden(ctx, name):
+    """one Cholesky of [[K + sI, .], [K_s^T, K_ss + 1e-6 I]] against the reference's own outputs: LML, mean, sd, and the
+    posterior samples mu + L_ @ normals (GP_regression.py:153-155) with the reference's normals"""
+    g = golden(name)
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    lml, mu, sd, L_ = ctx.fit_predict_sample(X, y, Xs, float(g["sigma"]), float(g["ell"]), float(g["s"]), 1e-6)
+    assert abs(lml - g["lml"]) <= LML_RTOL * abs(g["lml"])
+    assert np.allclose(mu, g["mu"], rtol=0, atol=MU_ATOL) and np.allclose(sd, g["sd"], rtol=0, atol=SD_ATOL)
+    assert relmax(ctx.diag(), g["diagL"]) <= DIAG_RTOL and relmax(ctx.m(), g["m"]) <= M_RTOL
+    assert relmax(ctx.alpha(), g["alpha"]) <= ALPHA_RTOL
+    assert np.array_equal(L_, np.tril(L_))
+    fpost = mu.reshape(-1, 1) + L_ @ g["normals"]
+    assert np.allclose(fpost, g["f_post"], rtol=0, atol=FPOST_ATOL)
+    assert np.array_equal(ctx.post_chol(1e-6), L_)          # the resident factor, downloaded again
+
+
+@pytest.mark.parametrize("N,d,n", [(1, 1, 1), (130, 2, 1), (300, 1, 37), (200, 2, 300), (2048, 8, 200), (6500, 3, 129), (12200, 8, 700)])
+def test_fit_predict_sample_one_pass_matches_the_separate_steps(ctx, oracle, N, d, n):
+    """the augmented factorisation against fit + predict + post_chol: the same numbers to rounding (block boundaries and the
+    leading dimension differ, so not bit for bit), on both sides of the lookahead threshold, more test than training points
+    included; every later call (alpha, the gradient, a second predict, post_chol with another jitter) works on its result"""
+    X, y, Xs = oracle.synthetic_problem(N, d, n, seed=13)
+    lml2 = ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    mu2, var2 = ctx.predict(Xs, want_sd=False)
+    a2, m2 = ctx.alpha(), ctx.m()
+    P2 = ctx.post_chol(1e-6)
+    P2b = ctx.post_chol(1e-3)
+    g2 = ctx.lml_grad() if N <= 2048 else None
+    lml1, mu1, var1, P1 = ctx.fit_predict_sample(X, y, Xs, 1.0, 2.0, 5e-4, 1e-6, want_sd=False)
+    amax = max(1.0, np.abs(a2).max())
+    assert abs(lml1 - lml2) <= 1e-11 * max(abs(lml2), np.sum(m2 * m2))
+    assert np.max(np.abs(ctx.m() - m2)) <= 1e-11 * max(1.0, np.abs(m2).max())
+    assert np.max(np.abs(ctx.alpha() - a2)) <= 1e-9 * amax
+    assert np.max(np.abs(mu1 - mu2)) <= 1e-10 * max(1.0, amax * 1e-3) and np.max(np.abs(var1 - var2)) <= 1e-11
+    assert np.array_equal(P1, np.tril(P1))
+    assert np.max(np.abs(P1 - P2)) <= 1e-6 * max(1.0, np.abs(P2).max())       # factors of a matrix with pivots of ~1e-6
+    assert np.max(np.abs(P1 @ P1.T - P2 @ P2.T)) <= 1e-10                     # the posterior covariance itself
+    assert np.max(np.abs(ctx.post_chol(1e-3) - P2b)) <= 1e-8 * max(1.0, np.abs(P2b).max())   # another jitter: computed, not fetched
+    if g2 is not None:
+        g1 = ctx.lml_grad()
+        assert np.allclose(g1, g2, rtol=1e-9, atol=1e-9 * max(1.0, np.abs(g2).max()))
+    mu3, var3 = ctx.predict_resident(want_sd=False)                           # the two-call predict on the augmented factor
+    assert np.max(np.abs(mu3 - mu2)) <= 1e-10 * max(1.0, amax * 1e-3) and np.max(np.abs(var3 - var2)) <= 1e-11
+    lml4 = ctx.factorize(1.0, 2.0, 5e-4)                                      # and back to the plain layout
+    assert lml4 == lml2 and np.array_equal(ctx.m(), m2)
+
+
+def test_fit_predict_sample_one_pass_errors(ctx, oracle):
+    """LinAlgError for a pivot of K + sI (GP_regression.py:138) and for one of the posterior covariance (:154), like the
+    separate steps; no test set -> ValueError"""
+    from gaussian_process_amd import GPContext
+    X, y, Xs = oracle.synthetic_problem(400, 2, 60, seed=3)
+    with GPContext(0) as c2:
+        c2.set_train(X, y)
+        with pytest.raises(ValueError):
+            c2.fit_predict_sample_resident(1.0, 2.0, 5e-4, 1e-6)
+        c2.set_test(Xs)
+        with pytest.raises(np.linalg.LinAlgError):
+            c2.fit_predict_sample_resident(1.0, 2.0, -2.0, 1e-6)           # K + sI not positive definite
+        c2.factorize(1.0, 2.0, 5e-4)
+        c2.predict_resident()
+        with pytest.raises(np.linalg.LinAlgError) as e2:
+            c2.post_chol(-0.5)                                              # K_ss - 0.5 I - v^T v: not positive definite
+        with pytest.raises(np.linalg.LinAlgError) as e1:
+            c2.fit_predict_sample_resident(1.0, 2.0, 5e-4, -0.5)
+        assert str(e1.value) == str(e2.value)
+        lml, mu, sd, L_ = c2.fit_predict_sample_resident(1.0, 2.0, 5e-4, 1e-6)   # and the context still works
+        assert np.isfinite(lml) and np.all(np.isfinite(L_))
