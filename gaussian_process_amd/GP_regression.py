@@ -114,11 +114,14 @@ def prediction(X_train, X_test, y_train, kernel_choice, l, num_fun, *, sigma=SIG
         sg, ll = _select_kernel(ctx, kernel_choice, l, sigma)  # :125-136
         # :126-128, 138-148 and 153-154 in one pass: ONE Cholesky of [[K + sI, .], [K(X*, X), K_ss + jitter I]] -- the test
         # rows ride through it below the training rows, and its last n columns are L_ (gpmi_fit_predict_sample_resident)
-        lml, mu_post, stand_devi, L_ = ctx.fit_predict_sample(X_train, y_train, X_test, sg, ll, noise_var, jitter, want_sd=True)
+        lml, mu_post, stand_devi, _ = ctx.fit_predict_sample(X_train, y_train, X_test, sg, ll, noise_var, jitter, want_sd=True,
+                                                             want_factor=False)
         n = mu_post.shape[0]
+        normals = np.random.normal(size=(n, num_fun))          # :155, drawn on the host in the reference's order
+        LZ = ctx.post_sample(jitter, normals)                  # L_ stays on the device: n x num_fun crosses PCIe, not n x n
     finally:
         ctx.set_kernel('rbf')
-    f_post_fun = mu_post.reshape(-1, 1) + np.dot(L_, np.random.normal(size=(n, num_fun)))  # :155
+    f_post_fun = mu_post.reshape(-1, 1) + LZ               # :155
     if return_lml:
         return mu_post, stand_devi, f_post_fun, np.float64(lml)
     return mu_post, stand_devi, f_post_fun

@@ -60,6 +60,7 @@ SIGNATURES = {
     "gpmi_fit_predict_sample_resident": [_vp, C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(_i64), _dp, _dp,
                                          C.c_int, _dp],
     "gpmi_post_chol": [_vp, C.c_double, _dp, C.POINTER(_i64)],
+    "gpmi_post_sample": [_vp, C.c_double, _dp, _i64, _dp, C.POINTER(_i64)],
     "gpmi_lml_grad": [_vp, _dp, _dp],
     "gpmi_grad_trace": [_vp, _dp, _dp, _i64, _i64, C.c_double, C.c_double, _dp, _dp, _dp, _dp],
     "gpmi_lml_batch": [_vp, _dp, _i64, _dp, C.POINTER(C.c_int)],

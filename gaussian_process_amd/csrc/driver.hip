@@ -430,6 +430,7 @@ int factorize_impl(gpmi_ctx* c, double sigma, double ell, double noise_var, doub
         c->v_in_A = true;
         c->ldV = c->ldA;
         c->have_v = true;
+        ++c->v_gen;
         c->post_in_A = form == 3;
         c->post_jitter = jitter;
         meanvar_to_host(c, h, mu, out2, want_sd);

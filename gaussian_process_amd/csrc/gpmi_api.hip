@@ -465,6 +465,7 @@ int gpmi_predict_resident(gpmi_ctx* c, double* mu, double* out2, int want_sd) {
     HIP_TRY(hipStreamSynchronize(s));
     c->timers_collect();
     c->have_v = true;
+    ++c->v_gen;
     meanvar_to_host(c, h, mu, out2, want_sd);
     return GPMI_OK;
 }
@@ -636,23 +637,26 @@ int gpmi_grad_trace(gpmi_ctx* c, const double* a_in, const double* b_in, int64_t
     return rc;
 }
 
-int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot) {
-    if (!c || !L_out) return fail_arg("gpmi_post_chol: null argument");
+// the posterior-sample factor on the device: where cholesky(K_ss + jitter I - v^T v) of the resident test set sits (factor, ld)
+// -- behind L when it rode through the augmented factorisation (gpmi_fit_predict_sample_resident), else formed now in P
+// (K_ss build, v^T v by one MFMA SYRK, the same Cholesky) unless P already holds it for this jitter
+static int post_factor_device(gpmi_ctx* c, double jitter, const double** factor, int64_t* ld, int64_t* bad_pivot) {
     if (!c->have_v) return fail_arg("gpmi_post_chol: run gpmi_predict first");
-    HIP_TRY(hipSetDevice(c->device));
-    TuneScope tune_scope(&c->tune);
     hipStream_t s = c->stream;
-    c->timers_reset({GPMI_T_POSTCHOL});
     const int64_t np_ = c->np_, n = c->n;
+    if (bad_pivot) *bad_pivot = 0;
     if (c->post_in_A && c->v_in_A && jitter == c->post_jitter) {
-        // the factor rode through the augmented factorisation (gpmi_fit_predict_sample_resident): it sits behind L
-        HIP_TRY(c->dense.ensure((size_t)n * n * 8));
-        HIP_TRY(launch_extract(s, c->A.as<double>() + c->Np * c->ldA + c->Np, c->ldA, 0, n, 0, n, c->dense.as<double>(), 1));
-        HIP_TRY(hipMemcpyAsync(L_out, c->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (bad_pivot) *bad_pivot = 0;
+        *factor = c->A.as<double>() + c->Np * c->ldA + c->Np;
+        *ld = c->ldA;
         return GPMI_OK;
     }
+    if (c->post_in_P && jitter == c->post_jitter_P && c->post_gen_P == c->v_gen) {
+        *factor = c->P.as<double>();
+        *ld = c->ldP;
+        return GPMI_OK;
+    }
+    c->post_in_P = false;
+    c->timers_reset({GPMI_T_POSTCHOL});
     c->ldP = np_ + 32;
     HIP_TRY(c->P.ensure((size_t)np_ * c->ldP * 8));
     double* P = c->P.as<double>();
@@ -674,10 +678,7 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
     HIP_TRY(launch_gemm_nt(s, g));
     HIP_TRY(cholesky_inplace(c, P, c->ldP, np_, np_, c->info.as<int64_t>(), false));
     c->span_end(sp);
-    HIP_TRY(c->dense.ensure((size_t)n * n * 8));
-    HIP_TRY(launch_extract(s, P, c->ldP, 0, n, 0, n, c->dense.as<double>(), 1));
     int64_t info;
-    HIP_TRY(hipMemcpyAsync(L_out, c->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipMemcpyAsync(&info, c->info.p, sizeof info, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->timers_collect();
@@ -686,7 +687,53 @@ int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot
         g_err = "Matrix is not positive definite";
         return GPMI_ERR_NOT_PD;
     }
-    if (bad_pivot) *bad_pivot = 0;
+    c->post_in_P = true;
+    c->post_jitter_P = jitter;
+    c->post_gen_P = c->v_gen;
+    *factor = P;
+    *ld = c->ldP;
+    return GPMI_OK;
+}
+
+int gpmi_post_chol(gpmi_ctx* c, double jitter, double* L_out, int64_t* bad_pivot) {
+    if (!c || !L_out) return fail_arg("gpmi_post_chol: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
+    const double* F = nullptr;
+    int64_t ld = 0;
+    int rc = post_factor_device(c, jitter, &F, &ld, bad_pivot);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const int64_t n = c->n;
+    HIP_TRY(c->dense.ensure((size_t)n * n * 8));
+    HIP_TRY(launch_extract(s, F, ld, 0, n, 0, n, c->dense.as<double>(), 1));
+    HIP_TRY(hipMemcpyAsync(L_out, c->dense.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return GPMI_OK;
+}
+
+// L_ @ Z for the posterior samples f_post = mu + L_ @ normals (GP_regression.py:155) without bringing L_ to the host: Z
+// (n x num_fun row-major, the caller's normals -- drawn on the host so that np.random's order is the reference's) goes up,
+// the product comes down.  The factor is the one gpmi_post_chol(jitter) would return.
+int gpmi_post_sample(gpmi_ctx* c, double jitter, const double* Z, int64_t num_fun, double* LZ_out, int64_t* bad_pivot) {
+    if (!c || !Z || !LZ_out) return fail_arg("gpmi_post_sample: null argument");
+    if (num_fun <= 0 || num_fun > (1 << 20)) return fail_arg("gpmi_post_sample: num_fun must be in 1 .. 2^20");
+    HIP_TRY(hipSetDevice(c->device));
+    TuneScope tune_scope(&c->tune);
+    const double* F = nullptr;
+    int64_t ld = 0;
+    int rc = post_factor_device(c, jitter, &F, &ld, bad_pivot);
+    if (rc) return rc;
+    hipStream_t s = c->stream;
+    const int64_t n = c->n;
+    const size_t bytes = (size_t)n * (size_t)num_fun * 8;
+    HIP_TRY(c->dense.ensure(2 * bytes));
+    double* Zd = c->dense.as<double>();
+    double* Od = Zd + (size_t)n * (size_t)num_fun;
+    HIP_TRY(hipMemcpyAsync(Zd, Z, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_tri_mul(s, F, ld, Zd, n, num_fun, Od));
+    HIP_TRY(hipMemcpyAsync(LZ_out, Od, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return GPMI_OK;
 }
 

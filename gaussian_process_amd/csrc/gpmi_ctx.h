@@ -141,6 +141,9 @@ struct gpmi_ctx {
     double* m_row() { return A.as<double>() + yrow * ldA; }
     bool post_in_A = false;  // A[Np.., Np..] holds cholesky(K_ss + post_jitter I - v^T v) of the resident test set
     double post_jitter = 0.0;
+    bool post_in_P = false;  // ... or P does (gpmi_post_chol / gpmi_post_sample on a resident v), for post_jitter_P and the
+    double post_jitter_P = 0.0;   // v of generation post_gen_P (v_gen counts every (re)computation of v)
+    uint64_t v_gen = 0, post_gen_P = 0;
     std::vector<double> hXs; // host copy of the test inputs (diag(K_ss) of the linear kernel)
     Box boxX, boxXs;         // bounding boxes of the training / test inputs
     DevBuf Xs, V, P, vec, dense;

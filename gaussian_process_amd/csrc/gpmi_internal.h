@@ -193,6 +193,8 @@ hipError_t launch_set_identity_diag(hipStream_t s, double* V, int64_t ld, int64_
 
 // ---- solve.hip -------------------------------------------------------------
 // dot[i] = sum_j V[i][j]*m[j], sq[i] = sum_j V[i][j]^2, j < ncols (fixed order)
+// out (n x nf row-major) = tril(L) @ Z (n x nf row-major), L n x n with leading dimension ld: reads j <= i only
+hipError_t launch_tri_mul(hipStream_t s, const double* L, int64_t ld, const double* Z, int64_t n, int64_t nf, double* out);
 hipError_t launch_row_dots(hipStream_t s, const double* V, int64_t ld, int64_t nrows,
                            int64_t ncols, const double* m, double* dot, double* sq);
 // out[0] = sum_{i<n} log(A[i*(ld+1)]), out[1] = sum_{i<n} m[i]^2 (deterministic)

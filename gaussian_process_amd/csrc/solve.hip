@@ -51,6 +51,47 @@ __global__ __launch_bounds__(256) void row_dots_kernel(const double* V, int64_t 
     }
 }
 
+// LZ[i, f] = sum_{j <= i} L[i, j] * Z[j, f]: the posterior samples' L_ @ normals (GP_regression.py:155) with L_ left where
+// the factorisation put it.  Only j <= i is read, so what sits above the diagonal of the factor's tiles (the 16 x 16 inverses
+// of the fused leaves) does not matter.  One wave per row, lanes stride over the row, NF functions per pass; the 64 partial
+// sums of a row are added in a fixed tree (bitwise reproducible).  HBM read: 8 n (n + 1) / 2 bytes per NF functions.
+template <int NF>
+__global__ __launch_bounds__(256) void tri_mul_kernel(const double* __restrict__ L, int64_t ld, const double* __restrict__ Z,
+                                                      int64_t n, int nf, int f0, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 4 + w;
+    if (i >= n) return;                                         // wave-uniform
+    double acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = 0.0;
+    const double* Li = L + i * ld;
+    for (int64_t j = lane; j <= i; j += 64) {
+        const double l = Li[j];
+        const double* zj = Z + j * nf + f0;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+            if (f0 + f < nf) acc[f] = fma(l, zj[f], acc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        double v = acc[f];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && f0 + f < nf) out[i * nf + f0 + f] = v;
+    }
+}
+
+hipError_t launch_tri_mul(hipStream_t s, const double* L, int64_t ld, const double* Z, int64_t n, int64_t nf, double* out) {
+    if (n <= 0 || nf <= 0) return hipSuccess;
+    if (nf > (1 << 20) || n > ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    for (int64_t f0 = 0; f0 < nf; f0 += 8) {
+        hipLaunchKernelGGL(tri_mul_kernel<8>, dim3(grid), dim3(256), 0, s, L, ld, Z, n, (int)nf, (int)f0, out);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_row_dots(hipStream_t s, const double* V, int64_t ld, int64_t nrows,
                            int64_t ncols, const double* m, double* dot, double* sq) {
     if (nrows <= 0) return hipSuccess;

@@ -217,7 +217,7 @@ class GPContext:
         check(st, bad.value)
         return lml.value, mu, o2
 
-    def fit_predict_sample_resident(self, sigma, l, noise_var, jitter, want_sd=True):
+    def fit_predict_sample_resident(self, sigma, l, noise_var, jitter, want_sd=True, want_factor=True):
         """prediction() with its posterior-sample factor in one pass (GP_regression.py:109-156): ONE Cholesky of
         [[K + sI, .], [K(X*, X), K_ss + jitter I]] -- L, v^T and L_ = cholesky(K_ss + jitter I - v^T v) are its blocks.
         Returns (lml, mu, sd_or_var, L_)."""
@@ -225,17 +225,17 @@ class GPContext:
         bad = C.c_int64()
         mu = np.empty(self.n)
         o2 = np.empty(self.n)
-        L_ = np.empty((self.n, self.n))
+        L_ = np.empty((self.n, self.n)) if want_factor else None      # None: it stays on the device (post_sample, post_chol)
         st = self._lib.gpmi_fit_predict_sample_resident(self._h, scalar(sigma, "sigma"), scalar(l, "l"), scalar(noise_var, "noise_var"),
                                                         float(jitter), C.byref(lml), C.byref(bad), ptr(mu), ptr(o2),
-                                                        1 if want_sd else 0, ptr(L_))
+                                                        1 if want_sd else 0, ptr(L_) if want_factor else None)
         check(st, bad.value)
         return lml.value, mu, o2, L_
 
-    def fit_predict_sample(self, X, y, Xs, sigma, l, noise_var, jitter, want_sd=True):
+    def fit_predict_sample(self, X, y, Xs, sigma, l, noise_var, jitter, want_sd=True, want_factor=True):
         self.set_train(X, y)
         self.set_test(Xs)
-        return self.fit_predict_sample_resident(sigma, l, noise_var, jitter, want_sd)
+        return self.fit_predict_sample_resident(sigma, l, noise_var, jitter, want_sd, want_factor)
 
     def fit_predict(self, X, y, Xs, sigma, l, noise_var, want_sd=True):
         self.set_train(X, y)
@@ -246,6 +246,18 @@ class GPContext:
         out = np.empty((self.n, self.n))
         bad = C.c_int64()
         st = self._lib.gpmi_post_chol(self._h, float(jitter), ptr(out), C.byref(bad))
+        check(st, bad.value)
+        return out
+
+    def post_sample(self, jitter, Z):
+        """L_ @ Z with L_ = cholesky(K_ss + jitter I - v^T v) left on the device (GP_regression.py:154-155): Z (n, num_fun)
+        are the caller's normals; f_post = mu[:, None] + the result."""
+        Z = as_f64(Z, 2, "Z")
+        if Z.shape[0] != self.n:
+            raise ValueError("Z must have one row per test point: %s for n=%d" % (Z.shape, self.n))
+        out = np.empty_like(Z)
+        bad = C.c_int64()
+        st = self._lib.gpmi_post_sample(self._h, float(jitter), ptr(Z), Z.shape[1], ptr(out), C.byref(bad))
         check(st, bad.value)
         return out
 

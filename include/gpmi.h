@@ -175,6 +175,13 @@ int gpmi_fit_predict_sample_resident(gpmi_ctx* ctx, double sigma, double ell, do
  * diagonal.   */
 int gpmi_post_chol(gpmi_ctx* ctx, double jitter, double* L_out, int64_t* bad_pivot);
 
+/* L_ @ Z for f_post = mu + L_ @ normals (GP_regression.py:155) without bringing L_ (n x n) to the host: Z (n x num_fun
+ * row-major; the caller's normals, drawn on the host so that np.random's order stays the reference's) goes up, LZ_out
+ * (n x num_fun) comes down.  L_ is the factor gpmi_post_chol(jitter) returns -- the resident one when it rode through
+ * gpmi_fit_predict_sample_resident or an earlier call formed it for this jitter, else formed now (status and bad_pivot as
+ * gpmi_post_chol).  Row sums are added in a fixed order (bitwise reproducible); against np.dot they differ by rounding. */
+int gpmi_post_sample(gpmi_ctx* ctx, double jitter, const double* Z, int64_t num_fun, double* LZ_out, int64_t* bad_pivot);
+
 /* Gradient of the log marginal likelihood at the resident factorisation:
  *   d_ell   = .5 * trace((alpha alpha^T - K_y^-1) @ l_grad),     l_grad     = sigma^2 exp(-.5 sqdist/l^2) sqdist/l^3
  *                                                     tune_hyperparms_regression.py:54-57

@@ -1369,3 +1369,35 @@ def test_fit_predict_sample_one_pass_errors(ctx, oracle):
         assert str(e1.value) == str(e2.value)
         lml, mu, sd, L_ = c2.fit_predict_sample_resident(1.0, 2.0, 5e-4, 1e-6)   # and the context still works
         assert np.isfinite(lml) and np.all(np.isfinite(L_))
+
+
+@pytest.mark.parametrize("N,n,nf", [(1, 1, 1), (200, 37, 3), (700, 300, 10), (1500, 1100, 17), (300, 129, 8)])
+def test_post_sample_is_the_factor_times_the_normals(ctx, oracle, N, n, nf):
+    """gpmi_post_sample: L_ @ Z formed on the device (GP_regression.py:155) against the downloaded factor times the same Z,
+    with the factor behind L (augmented pass) and in P (two-call predict); another jitter, another test set and a refit
+    are noticed (the resident factor is never a stale one)"""
+    X, y, Xs = oracle.synthetic_problem(N, 3, n, seed=31)
+    rng = np.random.default_rng(7)
+    Z = rng.standard_normal((n, nf))
+
+    def close(a, b):
+        return np.max(np.abs(a - b)) <= 1e-13 * max(1.0, np.abs(b).max()) * max(1, n) ** 0.5
+
+    lml, mu, sd, L_ = ctx.fit_predict_sample(X, y, Xs, 1.0, 2.0, 5e-4, 1e-6)
+    assert close(ctx.post_sample(1e-6, Z), L_ @ Z)
+    assert np.array_equal(ctx.post_sample(1e-6, Z), ctx.post_sample(1e-6, Z))          # fixed summation order
+    L3 = ctx.post_chol(1e-3)                                                            # another jitter: formed in P
+    assert close(ctx.post_sample(1e-3, Z), L3 @ Z)
+    assert close(ctx.post_sample(1e-6, Z), L_ @ Z)                                      # the riding one is still there
+    ctx.fit(X, y, 1.0, 2.0, 5e-4)
+    ctx.predict(Xs)
+    S = ctx.post_sample(1e-6, Z)                                                        # two-call form: factor formed on demand
+    assert close(S, ctx.post_chol(1e-6) @ Z)
+    Xs2 = Xs + 0.05
+    ctx.predict(Xs2)                                                                    # a new v: P is stale and is rebuilt
+    S2 = ctx.post_sample(1e-6, Z)
+    assert close(S2, ctx.post_chol(1e-6) @ Z) and (n == 1 or not np.array_equal(S2, S))
+    with pytest.raises(ValueError):
+        ctx.post_sample(1e-6, Z[:-1] if n > 1 else np.zeros((2, nf)))
+    with pytest.raises(np.linalg.LinAlgError):
+        ctx.post_sample(-5.0, Z)
